@@ -1,0 +1,232 @@
+/*
+ * os2r.h — C-ABI of the MI355X-native batched monopod stepper.
+ *
+ * This is the drop-in boundary for the gym_os2r "env.step" hot path.  The
+ * reference reaches its physics backend through these Python->SWIG call sites
+ * (all paths relative to the reference checkout):
+ *
+ *   gym_os2r/runtimes/gazebo_runtime.py:70-77   10x { task.set_action(a); gazebo.run() }
+ *   gym_os2r/runtimes/gazebo_runtime.py:80-95   get_observation / get_reward / is_done / get_info
+ *   gym_os2r/runtimes/gazebo_runtime.py:111-114 scenario.GazeboSimulator(1/physics_rate, rtf, steps_per_run=1)
+ *   gym_os2r/tasks/monopod.py:225,234           model.set_joint_generalized_force_targets / ..._targets()
+ *   gym_os2r/tasks/monopod.py:248-249           model.joint_positions / joint_velocities
+ *   gym_os2r/randomizers/monopod.py:125-128     model.to_gazebo().reset_joint_positions / _velocities
+ *   gym_os2r/randomizers/monopod.py:60          world.to_gazebo().set_gravity
+ *   gym_os2r/randomizers/monopod.py:182-215     per-reset SDF randomisation (mass/friction/damping/mu)
+ *
+ * One Os2rSim owns the state of N independent environments resident in HBM
+ * (struct-of-arrays, one GPU lane per environment).  Every entry point returns
+ * an int status (0 = OK), never throws, and is stream-ordered on the hipStream_t
+ * passed as `void* stream` (NULL = the default stream).  All `*_dev` pointers
+ * are device pointers owned by the caller (e.g. torch tensors' data_ptr()); the
+ * library owns only its internal state.  A handle is not thread-safe.
+ *
+ * Plain C: no torch / pybind / HIP types appear in any signature.
+ */
+#ifndef OS2R_H_
+#define OS2R_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OS2R_ABI_VERSION 1
+
+#define OS2R_MAX_DOF 5      /* yaw, pitch, boom_connector, hip, knee                       */
+#define OS2R_MAX_CAND 192   /* ground-contact candidate points of one model                */
+#define OS2R_MAX_OBS 12     /* 5 pos + 5 vel + 2 measured torques                          */
+#define OS2R_MAX_RESET_POSES 8
+
+/* status codes */
+enum {
+  OS2R_OK = 0,
+  OS2R_ERR_INVALID = 1,   /* bad argument / inconsistent config                            */
+  OS2R_ERR_HIP = 2,       /* a HIP runtime call failed, see os2r_last_error                 */
+  OS2R_ERR_NO_DEVICE = 3, /* no gfx950 device visible                                       */
+  OS2R_ERR_ALLOC = 4
+};
+
+/* arithmetic type of the device path */
+enum { OS2R_F32 = 0, OS2R_F64 = 1 };
+
+/* ------------------------------------------------------------------------- *
+ * Compiled robot model: a serial chain of nq revolute joints hanging off the
+ * world, produced by the model compiler from a URDF (+ STL collision meshes)
+ * with fixed joints lumped into their parent body
+ * (gym_os2r/models/models/<variant>/<variant>.urdf).
+ * Joint i connects body i-1 (body -1 = world) to body i.
+ * ------------------------------------------------------------------------- */
+typedef struct Os2rModel {
+  int32_t nq;                          /* 2..5 degrees of freedom                            */
+  int32_t axis[OS2R_MAX_DOF];          /* joint axis in the joint frame: 0=x 1=y 2=z         */
+  double rfix[OS2R_MAX_DOF][9];        /* row-major rotation: joint frame in parent body     */
+  double rpos[OS2R_MAX_DOF][3];        /* joint origin in parent body frame [m]              */
+  double mass[OS2R_MAX_DOF];           /* (lumped) body mass [kg]                            */
+  double com[OS2R_MAX_DOF][3];         /* centre of mass in body frame [m]                   */
+  double icom[OS2R_MAX_DOF][6];        /* inertia about COM, body axes: xx xy xz yy yz zz    */
+  double damping[OS2R_MAX_DOF];        /* viscous joint damping [N m s/rad]                  */
+  double friction[OS2R_MAX_DOF];       /* Coulomb joint friction [N m]                       */
+  double mu[OS2R_MAX_DOF];             /* contact friction coefficient of body i vs ground   */
+  int32_t act_dof[2];                  /* dof index of hip_joint, knee_joint                 */
+  double max_torque[2];                /* [N m], settings.yaml spaces/action                 */
+  double gravity_z;                    /* world gravity along z [m/s^2] (negative)           */
+  int32_t ncand;                       /* number of contact candidate points                 */
+  int32_t cand_body[OS2R_MAX_CAND];    /* body index of each candidate, non-decreasing       */
+  double cand_p[OS2R_MAX_CAND][3];     /* candidate position in its body frame [m]           */
+} Os2rModel;
+
+/* observation slot kinds (gym_os2r/tasks/monopod.py:238-272, monopod_no_norm.py:222-246) */
+enum {
+  OS2R_OBS_POS_NORM = 0,       /* 2*(x-low)/(high-low)-1                                   */
+  OS2R_OBS_POS_PERIODIC_NORM,  /* wrap to [-pi,pi) then the affine map                     */
+  OS2R_OBS_VEL_TANH,           /* tanh(0.05*v)                                              */
+  OS2R_OBS_TORQUE_NORM,        /* previous action through the affine map (low=-1, high=1)  */
+  OS2R_OBS_POS_RAW,            /* no_norm task: x                                           */
+  OS2R_OBS_POS_PERIODIC_RAW,   /* no_norm task: wrap only                                   */
+  OS2R_OBS_VEL_RAW,            /* no_norm task: v                                           */
+  OS2R_OBS_TORQUE_RAW          /* no_norm task: previous action                             */
+};
+
+/* reward ids (gym_os2r/rewards/__init__.py) */
+enum {
+  OS2R_REWARD_BALANCING_V1 = 0, /* :66-81  (StandingV1 :135-149 is the same formula)        */
+  OS2R_REWARD_BALANCING_V2 = 1, /* :83-101                                                   */
+  OS2R_REWARD_BALANCING_V3 = 2, /* :103-131                                                  */
+  OS2R_REWARD_STANDING_V1 = 3,
+  OS2R_REWARD_HOPPING_V1 = 4,   /* :151-180                                                  */
+  OS2R_REWARD_STRAIGHT_V1 = 5   /* :183-207                                                  */
+};
+
+/* reset modes */
+enum {
+  OS2R_RESET_FIXED = 0,   /* MonopodEnvNoRandomizer (randomizers/monopod_no_rand.py:59-98)  */
+  OS2R_RESET_RANDOM = 1   /* MonopodEnvRandomizer   (randomizers/monopod.py:89-128,182-215) */
+};
+
+typedef struct Os2rTaskSpec {
+  int32_t obs_dim;
+  int32_t obs_kind[OS2R_MAX_OBS];
+  int32_t obs_src[OS2R_MAX_OBS];   /* dof index (pos/vel kinds) or action index (torque)    */
+  double obs_low[OS2R_MAX_OBS];    /* normalisation limits (periodic: -(pi+eps))            */
+  double obs_high[OS2R_MAX_OBS];
+  double done_lo[OS2R_MAX_OBS];    /* done iff !(done_lo <= y <= done_hi), y = value before */
+  double done_hi[OS2R_MAX_OBS];    /*   the affine/tanh map (after the periodic wrap)       */
+  int32_t reward_id;
+  int32_t normalized;              /* 1: MonopodTask, 0: monopod_no_norm.MonopodTask        */
+  int32_t idx_pitch_pos;           /* obs indices the rewards read; -1 if masked/absent     */
+  int32_t idx_yaw_vel;
+  int32_t idx_hip_pos;
+  int32_t idx_knee_pos;
+  int32_t max_episode_steps;       /* gym TimeLimit (gym_os2r/__init__.py:19,56); 0 = none  */
+  /* reset */
+  int32_t reset_mode;
+  int32_t n_reset_poses;
+  int32_t reset_pose_id[OS2R_MAX_RESET_POSES];   /* index into the settings 'resets' table  */
+  int32_t reset_laying[OS2R_MAX_RESET_POSES];
+  double reset_pitch[OS2R_MAX_RESET_POSES];
+  double reset_hip[OS2R_MAX_RESET_POSES];        /* precomputed IK (utils/reset.py) or 1.57 */
+  double reset_knee[OS2R_MAX_RESET_POSES];
+  int32_t reset_simple;            /* 1: task_mode 'simple' (hip,knee ~ U(-1,1), quirk)     */
+  double leg_def[6];               /* ul, ll, cph, lb, hip_offset, clipping_adjust [mm]     */
+  int32_t dof_yaw, dof_pitch, dof_bc, dof_hip, dof_knee; /* chain dof index or -1           */
+  /* domain randomisation (randomizers/monopod.py:56-61,182-215); used when reset_mode==1  */
+  int32_t randomize_params;        /* 1: resample mass/friction/damping/mu at every reset   */
+  double dr_mass_lo, dr_mass_hi;          /* coefficient, U(0.8,1.2)                        */
+  double dr_friction_lo, dr_friction_hi;  /* absolute,    U(0.01,0.05)                      */
+  double dr_damping_lo, dr_damping_hi;    /* coefficient, U(0.8,1.2), zeros ignored         */
+  double dr_mu_base, dr_mu_lo, dr_mu_hi;  /* 0.33 * U(0.8,1.2)                              */
+  double dr_gravity_mean, dr_gravity_std; /* N(-9.8,0.2), drawn once at create              */
+} Os2rTaskSpec;
+
+typedef struct Os2rConfig {
+  int32_t abi_version;     /* must be OS2R_ABI_VERSION                                      */
+  int32_t dtype;           /* OS2R_F32 / OS2R_F64                                            */
+  int64_t num_envs;        /* environments owned by this handle (this rank's shard)          */
+  int64_t env_offset;      /* global index of local env 0 (multi-GPU sharding; RNG key)      */
+  uint64_t seed;
+  int32_t device;          /* HIP device ordinal                                             */
+  int32_t substeps;        /* physics_rate/agent_rate = 10 (runtimes/gazebo_runtime.py:46)   */
+  double dt;               /* 1/physics_rate = 1e-4 s                                        */
+  int32_t contact;         /* 0: ground contact off (bring-up config C2), 1: on              */
+  int32_t pgs_iters;       /* projected Gauss-Seidel sweeps per substep                      */
+  int32_t auto_reset;      /* SubprocVecEnv semantics (common/vec_env/subproc_vec_env.py:15) */
+  double erp;              /* contact error-reduction parameter                              */
+  double max_erv;          /* cap on the error-reduction velocity [m/s]                      */
+  Os2rModel model;
+  Os2rTaskSpec task;
+} Os2rConfig;
+
+/* per-environment parameter arrays, SoA [count][num_envs] in the handle's dtype */
+enum {
+  OS2R_PARAM_MASS_SCALE = 0, /* [nq]  body mass coefficient                                 */
+  OS2R_PARAM_DAMPING = 1,    /* [nq]  absolute damping                                       */
+  OS2R_PARAM_FRICTION = 2,   /* [nq]  absolute Coulomb friction                              */
+  OS2R_PARAM_MU = 3,         /* [nq]  body-vs-ground friction coefficient                    */
+  OS2R_PARAM_GRAVITY = 4     /* [1]   gravity_z                                              */
+};
+
+typedef struct Os2rSim Os2rSim;
+
+int os2r_abi_version(void);
+
+/* Allocates device state for cfg->num_envs environments, initialises per-env
+ * parameters to the model's nominal values (gravity: N(mean,std) per env when
+ * task.reset_mode==OS2R_RESET_RANDOM) and performs a full reset. */
+int os2r_create(const Os2rConfig* cfg, Os2rSim** out);
+int os2r_destroy(Os2rSim* sim);
+
+/* Reset the environments whose mask byte is non-zero (mask_dev == NULL: all).
+ * Replaces GazeboEnvRandomizer.reset -> randomize_task -> task.reset_task.
+ * obs_dev (nullable) receives the [num_envs, obs_dim] observation of every env. */
+int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* stream);
+
+/* One env-step for every environment: `substeps` physics iterations with the
+ * action held, then observation, reward, done; done environments are reset in
+ * the same launch when auto_reset is set.  Replaces GazeboRuntime.step.
+ *   actions_dev  [num_envs,2] in the handle's dtype, values in [-1,1]
+ *                (NULL: draw U(-1,1) actions on device from the counter RNG)
+ *   obs_dev      [num_envs,obs_dim]   observation (post-reset if auto-reset)
+ *   reward_dev   [num_envs]
+ *   done_dev     [num_envs] uint8     bit0 done, bit1 TimeLimit truncation,
+ *                                     bit2 non-finite state guard
+ *   term_obs_dev [num_envs,obs_dim]   nullable; observation before auto-reset
+ *                                     (info['terminal_observation'])            */
+int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev,
+              uint8_t* done_dev, void* term_obs_dev, void* stream);
+
+/* State access in chain dof order, SoA [nq][num_envs], handle's dtype. */
+int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream);
+int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* stream);
+
+/* Action history: [2][num_envs] SoA; which=0 last applied action, 1 the one before
+ * (tasks/monopod.py:95-98,232-235).                                              */
+int os2r_get_action_history(Os2rSim* sim, int which, void* out_dev, void* stream);
+int os2r_set_action_history(Os2rSim* sim, int which, const void* in_dev, void* stream);
+
+/* Per-env parameter arrays (domain randomisation), SoA [count][num_envs]. */
+int os2r_set_params(Os2rSim* sim, int field, const void* src_dev, void* stream);
+int os2r_get_params(Os2rSim* sim, int field, void* dst_dev, void* stream);
+
+/* Episode bookkeeping: elapsed steps (int32), episode index (uint32), reset pose
+ * id (uint8, info['reset_orientation']); any pointer may be NULL.               */
+int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_dev,
+                          uint8_t* pose_dev, void* stream);
+
+/* Global step counter that keys the on-device action RNG. */
+int os2r_get_step_count(Os2rSim* sim, uint64_t* out);
+int os2r_set_step_count(Os2rSim* sim, uint64_t value);
+
+/* Timing helper for benchmarks: runs `nsteps` os2r_step launches with on-device
+ * random actions on the given stream, bracketed by HIP events recorded on that
+ * stream; returns the elapsed GPU time in milliseconds. Outputs go to internal
+ * scratch buffers.                                                               */
+int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
+
+const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OS2R_H_ */

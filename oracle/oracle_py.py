@@ -1,0 +1,215 @@
+"""ctypes access to the CPU oracle (oracle/libos2r_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under gym-os2r_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libos2r_oracle.so")
+    src = os.path.join(_HERE, "os2r_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libos2r_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_tolerance.restype = C.c_double
+        _LIB.orc_tolerance.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+        _LIB.orc_wrap.restype = C.c_double
+        _LIB.orc_wrap.argtypes = [C.c_double]
+        _LIB.orc_reward.restype = C.c_double
+        _LIB.orc_get_step_count.restype = C.c_uint64
+        _LIB.orc_set_step_count.argtypes = [C.c_void_p, C.c_uint64]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def uniform2(seed, env, stream, ctr, blk):
+    u = (C.c_double * 2)()
+    lib().orc_uniform2(C.c_uint64(seed), C.c_uint32(env), C.c_uint32(stream), C.c_uint32(ctr),
+                       C.c_uint32(blk), u)
+    return float(u[0]), float(u[1])
+
+
+def tolerance(x, lower, upper, margin, sigmoid, value_at_margin):
+    return lib().orc_tolerance(x, lower, upper, margin, int(sigmoid), value_at_margin)
+
+
+def leg_joint_angles(def6, pitch):
+    d = (C.c_double * 6)(*[float(v) for v in def6])
+    o = (C.c_double * 2)()
+    lib().orc_leg_joint_angles(d, C.c_double(pitch), o)
+    return float(o[0]), float(o[1])
+
+
+def observe(task_struct, q, qd, hist1):
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    qd = np.ascontiguousarray(qd, dtype=np.float64)
+    h = np.ascontiguousarray(hist1, dtype=np.float64)
+    obs = np.zeros(task_struct.obs_dim)
+    lib().orc_observe(C.byref(task_struct), _p(q), _p(qd), _p(h), _p(obs))
+    return obs
+
+
+def done(task_struct, obs):
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    return bool(lib().orc_done(C.byref(task_struct), _p(obs)))
+
+
+def reward(task_struct, obs, a0, a1):
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    a0 = np.ascontiguousarray(a0, dtype=np.float64)
+    a1 = np.ascontiguousarray(a1, dtype=np.float64)
+    return float(lib().orc_reward(C.byref(task_struct), _p(obs), _p(a0), _p(a1)))
+
+
+def dynamics(model_struct, q, qd, tau_full, dt=1e-4, mass_scale=None, damping=None, gravity_z=None):
+    """-> qdd[nq], minv[nq,nq], rw[nq,3,3], ow[nq,3] for one environment."""
+    n = model_struct.nq
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    qd = np.ascontiguousarray(qd, dtype=np.float64)
+    tau = np.ascontiguousarray(tau_full, dtype=np.float64)
+    ms = None if mass_scale is None else np.ascontiguousarray(mass_scale, dtype=np.float64)
+    dm = None if damping is None else np.ascontiguousarray(damping, dtype=np.float64)
+    g = model_struct.gravity_z if gravity_z is None else gravity_z
+    qdd, minv = np.zeros(n), np.zeros((n, n))
+    rw, ow = np.zeros((n, 9)), np.zeros((n, 3))
+    lib().orc_dynamics(C.byref(model_struct), C.c_double(dt), _p(ms), _p(dm), C.c_double(g),
+                       _p(q), _p(qd), _p(tau), _p(qdd), _p(minv), _p(rw), _p(ow))
+    return qdd, minv, rw.reshape(n, 3, 3), ow
+
+
+def contact_points(model_struct, rw, ow):
+    n = model_struct.nq
+    rw = np.ascontiguousarray(rw, dtype=np.float64).reshape(n, 9)
+    ow = np.ascontiguousarray(ow, dtype=np.float64)
+    active = np.zeros(n, dtype=np.int32)
+    pw, depth = np.zeros((n, 3)), np.zeros(n)
+    lib().orc_contact_points(C.byref(model_struct), _p(rw), _p(ow), _p(active), _p(pw), _p(depth))
+    return active.astype(bool), pw, depth
+
+
+def substep(cfg, q, qd, tau2, mass_scale=None, damping=None, friction=None, mu=None, gravity_z=None):
+    q = np.array(q, dtype=np.float64)
+    qd = np.array(qd, dtype=np.float64)
+    t = np.ascontiguousarray(tau2, dtype=np.float64)
+    arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+            for a in (mass_scale, damping, friction, mu)]
+    g = cfg.model.gravity_z if gravity_z is None else gravity_z
+    lib().orc_substep(C.byref(cfg), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]),
+                      C.c_double(g), _p(q), _p(qd), _p(t))
+    return q, qd
+
+
+class OracleSim:
+    """Batched oracle with the semantics of the C-ABI (host numpy arrays, SoA state)."""
+
+    def __init__(self, cfg, threads: int = 1):
+        self.cfg = cfg
+        self.N = int(cfg.num_envs)
+        self.nq = int(cfg.model.nq)
+        self.D = int(cfg.task.obs_dim)
+        self._h = C.c_void_p()
+        rc = lib().orc_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"orc_create failed: {rc}")
+        lib().orc_set_threads(self._h, int(threads))
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.N, self.D))
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        lib().orc_reset(self._h, _p(m), _p(obs))
+        return obs
+
+    def step(self, actions=None):
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
+        obs, term = np.zeros((self.N, self.D)), np.zeros((self.N, self.D))
+        rew, done_ = np.zeros(self.N), np.zeros(self.N, dtype=np.uint8)
+        lib().orc_step(self._h, _p(a), _p(obs), _p(rew), _p(done_), _p(term))
+        return obs, rew, done_, term
+
+    def get_state(self):
+        q, qd = np.zeros((self.nq, self.N)), np.zeros((self.nq, self.N))
+        lib().orc_get_state(self._h, _p(q), _p(qd))
+        return q, qd
+
+    def set_state(self, q, qd):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        qd = np.ascontiguousarray(qd, dtype=np.float64)
+        assert q.shape == (self.nq, self.N) and qd.shape == (self.nq, self.N)
+        lib().orc_set_state(self._h, _p(q), _p(qd))
+
+    def get_action_history(self, which):
+        out = np.zeros((2, self.N))
+        lib().orc_get_action_history(self._h, int(which), _p(out))
+        return out
+
+    def set_action_history(self, which, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        assert arr.shape == (2, self.N)
+        lib().orc_set_action_history(self._h, int(which), _p(arr))
+
+    def get_params(self, field):
+        count = 1 if field == 4 else self.nq
+        out = np.zeros((count, self.N))
+        lib().orc_get_params(self._h, int(field), _p(out))
+        return out
+
+    def set_params(self, field, arr):
+        count = 1 if field == 4 else self.nq
+        arr = np.ascontiguousarray(arr, dtype=np.float64).reshape(count, self.N)
+        lib().orc_set_params(self._h, int(field), _p(arr))
+
+    def episode_info(self):
+        steps = np.zeros(self.N, dtype=np.int32)
+        epi = np.zeros(self.N, dtype=np.uint32)
+        pose = np.zeros(self.N, dtype=np.uint8)
+        lib().orc_get_episode_info(self._h, _p(steps), _p(epi), _p(pose))
+        return steps, epi, pose
+
+    @property
+    def step_count(self):
+        return int(lib().orc_get_step_count(self._h))
+
+    @step_count.setter
+    def step_count(self, v):
+        lib().orc_set_step_count(self._h, C.c_uint64(int(v)))

@@ -1,0 +1,751 @@
+/*
+ * os2r_oracle.c — CPU restatement (scalar fp64, plain C) of the gym-os2r env-step path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under gym-os2r_amd/ may include, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / reported CPU baseline.
+ *
+ * What is restated, and from where (paths relative to the reference checkout):
+ *
+ *   env-step loop      gym_os2r/runtimes/gazebo_runtime.py:65-97 (10 substeps, action held :70-77)
+ *   set_action         gym_os2r/tasks/monopod.py:202-236
+ *   observation        gym_os2r/tasks/monopod.py:238-272, tasks/monopod_no_norm.py:222-246
+ *   done               gym_os2r/tasks/monopod.py:274-298 (reset_space :198)
+ *   rewards            gym_os2r/rewards/__init__.py:66-207, rewards/rewards_utils.py:10-122
+ *   reset / IK         gym_os2r/randomizers/monopod_no_rand.py:59-98,
+ *                      gym_os2r/randomizers/monopod.py:89-128, gym_os2r/utils/reset.py:4-40
+ *   randomisation      gym_os2r/randomizers/monopod.py:56-61,182-215
+ *   vec-env semantics  gym_os2r/common/vec_env/subproc_vec_env.py:15-21 (auto-reset)
+ *
+ * PARITY PINNING.  The epilogue (observation / reward / done), tolerance() and the
+ * reset IK are pinned by golden vectors generated from the reference's own Python
+ * (tests/golden/, tools/gen_golden.py).  The physics of one iteration
+ * (`gazebo.run()`, gazebo_runtime.py:76) lives in third-party code that is not in
+ * the reference checkout (gym-ignition -> ScenarIO -> Ignition Gazebo ->
+ * ign-physics-dartsim -> DART, all unpinned in setup.py:22-26) and cannot be built
+ * or imported here: for the dynamics this oracle is PARITY UNPINNED.  It restates
+ * the published scheme of that stack — Featherstone's articulated-body algorithm
+ * with joint damping taken implicitly in the articulated-inertia projection,
+ * semi-implicit Euler, then velocity-level constraint impulses (frictional ground
+ * contact + per-dof Coulomb joint friction as a boxed LCP), then position update —
+ * and is checked by independent known answers and by
+ * invariants (tests/test_oracle_dynamics.py).
+ *
+ * The dynamics here use dense 6x6 spatial algebra (Featherstone, "Rigid Body
+ * Dynamics Algorithms", 2008, Table 7.1 and ch.2 notation) on purpose: the HIP
+ * kernels use hand-specialised sparse forms, so agreement is a meaningful check.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/os2r.h"
+#include "os2r_oracle.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- *
+ * Counter RNG: Philox4x32-10 (Salmon et al., SC'11, "Parallel random numbers:
+ * as easy as 1, 2, 3"; Random123).  Known answers are checked in
+ * tests/test_oracle_rng.py.
+ * ------------------------------------------------------------------------- */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* 53-bit uniform in [0,1) from two 32-bit words */
+static double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+/* two uniforms of block `blk` of (env, stream, ctr) */
+void orc_uniform2(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr, uint32_t blk,
+                  double u[2]) {
+  uint32_t c[4] = {env, stream, ctr, blk};
+  uint32_t k[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+  uint32_t o[4];
+  orc_philox4x32_10(c, k, o);
+  u[0] = u53(o[0], o[1]);
+  u[1] = u53(o[2], o[3]);
+}
+
+/* Box-Muller pair of standard normals from one block */
+static void normal2(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr, uint32_t blk,
+                    double z[2]) {
+  double u[2];
+  orc_uniform2(seed, env, stream, ctr, blk, u);
+  double r = sqrt(-2.0 * log(1.0 - u[0]));
+  double th = 6.283185307179586476925286766559 * u[1];
+  z[0] = r * cos(th);
+  z[1] = r * sin(th);
+}
+
+enum { STREAM_ACTION = 1, STREAM_RESET = 2, STREAM_PARAMS = 3, STREAM_GRAVITY = 4 };
+
+/* ------------------------------------------------------------------------- *
+ * rewards_utils.py:10-73  _sigmoids ; :76-122 tolerance
+ * sigmoid ids: 0 gaussian 1 hyperbolic 2 long_tail 3 reciprocal 4 cosine
+ *              5 linear 6 quadratic 7 tanh_squared
+ * ------------------------------------------------------------------------- */
+static double sigmoid_value(double x, double value_at_1, int sigmoid) {
+  switch (sigmoid) {
+    case 0: { double scale = sqrt(-2.0 * log(value_at_1)); double t = x * scale; return exp(-0.5 * (t * t)); }
+    case 1: { double scale = acosh(1.0 / value_at_1); return 1.0 / cosh(x * scale); }
+    case 2: { double scale = sqrt(1.0 / value_at_1 - 1.0); double t = x * scale; return 1.0 / (t * t + 1.0); }
+    case 3: { double scale = 1.0 / value_at_1 - 1.0; return 1.0 / (fabs(x) * scale + 1.0); }
+    case 4: { double scale = acos(2.0 * value_at_1 - 1.0) / M_PI; double sx = x * scale;
+              return fabs(sx) < 1.0 ? (1.0 + cos(M_PI * sx)) / 2.0 : 0.0; }
+    case 5: { double scale = 1.0 - value_at_1; double sx = x * scale; return fabs(sx) < 1.0 ? 1.0 - sx : 0.0; }
+    case 6: { double scale = sqrt(1.0 - value_at_1); double sx = x * scale; return fabs(sx) < 1.0 ? 1.0 - sx * sx : 0.0; }
+    case 7: { double scale = atanh(sqrt(1.0 - value_at_1)); double t = tanh(x * scale); return 1.0 - t * t; }
+    default: return NAN;
+  }
+}
+
+double orc_tolerance(double x, double lower, double upper, double margin, int sigmoid,
+                     double value_at_margin) {
+  int in_bounds = (lower <= x) && (x <= upper);
+  if (margin == 0.0) return in_bounds ? 1.0 : 0.0;
+  double d = (x < lower ? lower - x : x - upper) / margin;
+  return in_bounds ? 1.0 : sigmoid_value(d, value_at_margin, sigmoid);
+}
+
+/* utils/reset.py:4-40 — (hip, knee) that put the foot on the ground for a boom pitch.
+ * def6 = upper_leg_length, lower_leg_length, central_pivot_height, length_boom,
+ *        hip_offset, clipping_adjust (settings.yaml task_modes/<mode>/definition, mm) */
+void orc_leg_joint_angles(const double def6[6], double pitch, double out[2]) {
+  double ul = def6[0], ll = def6[1], cph = def6[2], lb = def6[3];
+  double lh = (lb * sin(pitch) + cph) / cos(pitch);
+  double lleg = lh - def6[4] - def6[5];
+  if (lleg > ul + ll) { out[0] = 0.0; out[1] = 0.0; return; }
+  double ua = acos((ul * ul + lleg * lleg - ll * ll) / (2.0 * ul * lleg));
+  double la = asin(ul * sin(ua) / ll) + ua;
+  out[0] = ua;
+  out[1] = -la;
+}
+
+/* numpy.mod(x + pi, 2*pi) - pi   (tasks/monopod.py:260-261) */
+static double py_mod(double a, double b) {
+  double m = fmod(a, b);
+  if (m != 0.0) { if ((b < 0.0) != (m < 0.0)) m += b; }
+  else m = copysign(0.0, b);
+  return m;
+}
+double orc_wrap(double x) { return py_mod(x + M_PI, 2.0 * M_PI) - M_PI; }
+
+/* ------------------------------------------------------------------------- *
+ * Observation (tasks/monopod.py:238-272) for one environment.
+ * hist1 = action_history[1] at the time of the call.
+ * ------------------------------------------------------------------------- */
+void orc_observe(const Os2rTaskSpec* ts, const double* q, const double* qd, const double hist1[2],
+                 double* obs) {
+  for (int d = 0; d < ts->obs_dim; ++d) {
+    int s = ts->obs_src[d];
+    double lo = ts->obs_low[d], hi = ts->obs_high[d];
+    double y;
+    switch (ts->obs_kind[d]) {
+      case OS2R_OBS_POS_NORM:          y = q[s]; obs[d] = 2.0 * (y - lo) / (hi - lo) - 1.0; break;
+      case OS2R_OBS_POS_PERIODIC_NORM: y = orc_wrap(q[s]); obs[d] = 2.0 * (y - lo) / (hi - lo) - 1.0; break;
+      case OS2R_OBS_VEL_TANH:          obs[d] = tanh(0.05 * qd[s]); break;
+      case OS2R_OBS_TORQUE_NORM:       y = hist1[s]; obs[d] = 2.0 * (y - lo) / (hi - lo) - 1.0; break;
+      case OS2R_OBS_POS_RAW:           obs[d] = q[s]; break;
+      case OS2R_OBS_POS_PERIODIC_RAW:  obs[d] = orc_wrap(q[s]); break;
+      case OS2R_OBS_VEL_RAW:           obs[d] = qd[s]; break;
+      case OS2R_OBS_TORQUE_RAW:        obs[d] = hist1[s]; break;
+      default: obs[d] = NAN;
+    }
+  }
+}
+
+/* tasks/monopod.py:274-298: done = observation outside reset_space, evaluated the
+ * reference's way on the observation itself: reset_space = Box(low+eps, high-eps)
+ * with low/high = -1/+1 (normalised task, :183-184,198) or the raw limits
+ * (monopod_no_norm.py).  gym Box.contains is all(x>=low) and all(x<=high). */
+int orc_done(const Os2rTaskSpec* ts, const double* obs) {
+  const double eps = 2.220446049250313e-16;
+  int done = 0;
+  for (int d = 0; d < ts->obs_dim; ++d) {
+    double lo, hi;
+    if (ts->normalized) { lo = -1.0 + eps; hi = 1.0 - eps; }
+    else { lo = ts->obs_low[d] + eps; hi = ts->obs_high[d] - eps; }
+    if (!(obs[d] >= lo) || !(obs[d] <= hi)) done = 1;
+  }
+  return done;
+}
+
+/* rewards/__init__.py.  a0 = actions[0] (current), a1 = actions[1] (previous). */
+double orc_reward(const Os2rTaskSpec* ts, const double* obs, const double a0[2], const double a1[2]) {
+  double nrm = ts->normalized ? 1.0 : 0.0;
+  double H = 0.11 / 1.57 * nrm + 0.11 * (1.0 - nrm);   /* _BALANCE_HEIGHT :77 */
+  double bp = ts->idx_pitch_pos >= 0 ? obs[ts->idx_pitch_pos] : NAN;
+  switch (ts->reward_id) {
+    case OS2R_REWARD_BALANCING_V1:
+    case OS2R_REWARD_STANDING_V1:
+      return orc_tolerance(bp, H, 4.0 * H, 0.0, 0, 0.1);
+    case OS2R_REWARD_BALANCING_V2: {
+      double bal = orc_tolerance(bp, H, 4.0 * H, 0.0, 0, 0.1);
+      double s0 = orc_tolerance(a0[0], 0.0, 0.0, 1.0, 6, 0.4);
+      double s1 = orc_tolerance(a0[1], 0.0, 0.0, 1.0, 6, 0.4);
+      return bal * (s0 * s1);
+    }
+    case OS2R_REWARD_BALANCING_V3: {
+      double bal = orc_tolerance(bp, H, 4.0 * H, 0.01, 2, 0.1);
+      double s0 = orc_tolerance(a0[0] - a1[0], 0.0, 0.0, 1.0, 6, 0.1);
+      double s1 = orc_tolerance(a0[1] - a1[1], 0.0, 0.0, 1.0, 6, 0.1);
+      return bal * (s0 * s1);
+    }
+    case OS2R_REWARD_HOPPING_V1: {
+      double bal = orc_tolerance(bp, H, 4.0 * H, 0.0, 0, 0.1);
+      double s0 = orc_tolerance(a0[0] - a1[0], 0.0, 0.0, 0.1, 6, 0.0);
+      double s1 = orc_tolerance(a0[1] - a1[1], 0.0, 0.0, 0.1, 6, 0.0);
+      double hv = ts->idx_yaw_vel >= 0 ? obs[ts->idx_yaw_vel] : NAN;
+      double move = orc_tolerance(hv, 0.25, 0.3, 0.15, 7, 0.1);
+      return bal * (s0 * s1) * move;
+    }
+    case OS2R_REWARD_STRAIGHT_V1: {
+      double s0 = orc_tolerance(a0[0] / 20.0, 0.0, 0.0, 1.0, 6, 0.0);
+      double s1 = orc_tolerance(a0[1] / 20.0, 0.0, 0.0, 1.0, 6, 0.0);
+      double sc = (s0 + s1) / 2.0;            /* ndarray.mean() of two elements */
+      sc = (4.0 + sc) / 5.0;
+      double hip = obs[ts->idx_hip_pos], knee = obs[ts->idx_knee_pos];
+      double hr = orc_tolerance(hip, 0.0, 0.0, 1.0, 5, 0.1);
+      double kr = orc_tolerance(knee, 0.0, 0.0, 1.0, 5, 0.1);
+      return hr * kr * sc;
+    }
+    default: return NAN;
+  }
+}
+
+/* ------------------------------------------------------------------------- *
+ * Dense spatial algebra (6-vectors [angular; linear], 6x6 row-major matrices).
+ * ------------------------------------------------------------------------- */
+typedef double V6[6];
+typedef double M6[36];
+typedef double M3[9];
+
+static void m3_mul(const M3 a, const M3 b, M3 c) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    double s = 0; for (int k = 0; k < 3; ++k) s += a[3 * i + k] * b[3 * k + j]; c[3 * i + j] = s; }
+}
+static void m3_transpose(const M3 a, M3 t) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t[3 * i + j] = a[3 * j + i]; }
+static void m3_vec(const M3 a, const double v[3], double o[3]) {
+  for (int i = 0; i < 3; ++i) o[i] = a[3 * i] * v[0] + a[3 * i + 1] * v[1] + a[3 * i + 2] * v[2];
+}
+static void skew(const double v[3], M3 s) {
+  s[0] = 0; s[1] = -v[2]; s[2] = v[1]; s[3] = v[2]; s[4] = 0; s[5] = -v[0]; s[6] = -v[1]; s[7] = v[0]; s[8] = 0;
+}
+static void cross3(const double a[3], const double b[3], double c[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static void axis_rot(int axis, double q, M3 r) {
+  double c = cos(q), s = sin(q);
+  for (int i = 0; i < 9; ++i) r[i] = 0;
+  if (axis == 0) { r[0] = 1; r[4] = c; r[5] = -s; r[7] = s; r[8] = c; }
+  else if (axis == 1) { r[4] = 1; r[0] = c; r[2] = s; r[6] = -s; r[8] = c; }
+  else { r[8] = 1; r[0] = c; r[1] = -s; r[3] = s; r[4] = c; }
+}
+static void m6_set_blocks(M6 m, const M3 a, const M3 b, const M3 c, const M3 d) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    m[6 * i + j] = a[3 * i + j]; m[6 * i + 3 + j] = b[3 * i + j];
+    m[6 * (i + 3) + j] = c[3 * i + j]; m[6 * (i + 3) + 3 + j] = d[3 * i + j]; }
+}
+static void m6_vec(const M6 m, const V6 v, V6 o) {
+  for (int i = 0; i < 6; ++i) { double s = 0; for (int k = 0; k < 6; ++k) s += m[6 * i + k] * v[k]; o[i] = s; }
+}
+static void m6t_vec(const M6 m, const V6 v, V6 o) {
+  for (int i = 0; i < 6; ++i) { double s = 0; for (int k = 0; k < 6; ++k) s += m[6 * k + i] * v[k]; o[i] = s; }
+}
+static void m6_mul(const M6 a, const M6 b, M6 c) {
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) {
+    double s = 0; for (int k = 0; k < 6; ++k) s += a[6 * i + k] * b[6 * k + j]; c[6 * i + j] = s; }
+}
+static void m6_transpose(const M6 a, M6 t) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) t[6 * i + j] = a[6 * j + i]; }
+static double dot6(const V6 a, const V6 b) { double s = 0; for (int i = 0; i < 6; ++i) s += a[i] * b[i]; return s; }
+
+/* motion cross product operator crm(v) and force operator crf(v) = -crm(v)^T (RBDA eq. 2.31-2.33) */
+static void crm(const V6 v, M6 m) {
+  M3 w, l, z = {0};
+  skew(v, w); skew(v + 3, l);
+  m6_set_blocks(m, w, z, l, w);
+}
+static void crf(const V6 v, M6 m) {
+  M6 c; crm(v, c);
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) m[6 * i + j] = -c[6 * j + i];
+}
+
+/* Plücker motion transform parent->child for rotation E (child<-parent) and child origin r
+ * in parent coordinates: X = [E 0; -E r^ , E]  (RBDA eq. 2.24-2.26) */
+static void plux(const M3 E, const double r[3], M6 X) {
+  M3 rs, Ers, mErs, z = {0};
+  skew(r, rs); m3_mul(E, rs, Ers);
+  for (int i = 0; i < 9; ++i) mErs[i] = -Ers[i];
+  m6_set_blocks(X, E, z, mErs, E);
+}
+
+/* spatial inertia about the body-frame origin (RBDA eq. 2.63) */
+static void spatial_inertia(double m, const double c[3], const double ic6[6], M6 I) {
+  M3 ic = {ic6[0], ic6[1], ic6[2], ic6[1], ic6[3], ic6[4], ic6[2], ic6[4], ic6[5]};
+  M3 cs, cst, ccT, a, b, bt, d = {0};
+  skew(c, cs); m3_transpose(cs, cst); m3_mul(cs, cst, ccT);
+  for (int i = 0; i < 9; ++i) { a[i] = ic[i] + m * ccT[i]; b[i] = m * cs[i]; bt[i] = m * cst[i]; }
+  d[0] = d[4] = d[8] = m;
+  m6_set_blocks(I, a, b, bt, d);
+}
+
+/* per-environment physical parameters */
+typedef struct {
+  double mass_scale[OS2R_MAX_DOF], damping[OS2R_MAX_DOF], friction[OS2R_MAX_DOF], mu[OS2R_MAX_DOF];
+  double gravity_z;
+} EnvParams;
+
+static void nominal_params(const Os2rModel* m, EnvParams* p) {
+  for (int i = 0; i < OS2R_MAX_DOF; ++i) {
+    p->mass_scale[i] = 1.0; p->damping[i] = m->damping[i]; p->friction[i] = m->friction[i]; p->mu[i] = m->mu[i];
+  }
+  p->gravity_z = m->gravity_z;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Articulated-body forward dynamics + inverse of the damping-augmented mass
+ * matrix, for one environment.  Outputs may be NULL.
+ *   qdd   [nq]       unconstrained acceleration
+ *   minv  [nq*nq]    (M + dt*diag(damping))^-1
+ *   rw    [nq][9]    world orientation of each body
+ *   ow    [nq][3]    world position of each body origin
+ * ------------------------------------------------------------------------- */
+static void dynamics(const Os2rModel* md, const EnvParams* ep, double dt, const double* q,
+                     const double* qd, const double* tau_full, double* qdd, double* minv,
+                     double (*rw)[9], double (*ow)[3]) {
+  const int n = md->nq;
+  M6 X[OS2R_MAX_DOF], IA[OS2R_MAX_DOF];
+  V6 S[OS2R_MAX_DOF], v[OS2R_MAX_DOF], c[OS2R_MAX_DOF], pA[OS2R_MAX_DOF], U[OS2R_MAX_DOF];
+  double D[OS2R_MAX_DOF], u[OS2R_MAX_DOF];
+
+  /* pass 1: kinematics, velocity-product terms, rigid-body inertias and bias forces */
+  for (int i = 0; i < n; ++i) {
+    M3 rq, rj, E;
+    M3 rf; memcpy(rf, md->rfix[i], sizeof(M3));
+    axis_rot(md->axis[i], q[i], rq);
+    m3_mul(rf, rq, rj);        /* child orientation in parent */
+    m3_transpose(rj, E);
+    plux(E, md->rpos[i], X[i]);
+    for (int k = 0; k < 6; ++k) S[i][k] = 0;
+    S[i][md->axis[i]] = 1.0;
+    V6 vj; for (int k = 0; k < 6; ++k) vj[k] = S[i][k] * qd[i];
+    if (i == 0) { for (int k = 0; k < 6; ++k) v[i][k] = vj[k]; }
+    else { V6 t; m6_vec(X[i], v[i - 1], t); for (int k = 0; k < 6; ++k) v[i][k] = t[k] + vj[k]; }
+    M6 cm; crm(v[i], cm); m6_vec(cm, vj, c[i]);
+    spatial_inertia(md->mass[i] * ep->mass_scale[i], md->com[i], md->icom[i], IA[i]);
+    V6 Iv; m6_vec(IA[i], v[i], Iv);
+    M6 cf; crf(v[i], cf); m6_vec(cf, Iv, pA[i]);
+    if (rw) {
+      if (i == 0) { memcpy(rw[0], rj, sizeof(M3)); memcpy(ow[0], md->rpos[0], 3 * sizeof(double)); }
+      else { m3_mul(rw[i - 1], rj, rw[i]); double t[3]; m3_vec(rw[i - 1], md->rpos[i], t);
+             for (int k = 0; k < 3; ++k) ow[i][k] = ow[i - 1][k] + t[k]; }
+    }
+  }
+  /* pass 2: articulated inertias, inward */
+  for (int i = n - 1; i >= 0; --i) {
+    m6_vec(IA[i], S[i], U[i]);
+    D[i] = dot6(S[i], U[i]) + dt * ep->damping[i];
+    u[i] = tau_full[i] - ep->damping[i] * qd[i] - dot6(S[i], pA[i]);
+    if (i > 0) {
+      M6 Ia, Xt, t1, t2; V6 pa, t;
+      for (int r = 0; r < 6; ++r) for (int s = 0; s < 6; ++s) Ia[6 * r + s] = IA[i][6 * r + s] - U[i][r] * U[i][s] / D[i];
+      m6_vec(Ia, c[i], t);
+      for (int k = 0; k < 6; ++k) pa[k] = pA[i][k] + t[k] + U[i][k] * u[i] / D[i];
+      m6_transpose(X[i], Xt); m6_mul(Xt, Ia, t1); m6_mul(t1, X[i], t2);
+      for (int k = 0; k < 36; ++k) IA[i - 1][k] += t2[k];
+      m6t_vec(X[i], pa, t);
+      for (int k = 0; k < 6; ++k) pA[i - 1][k] += t[k];
+    }
+  }
+  /* pass 3: accelerations, outward; the base accelerates upward by -g (RBDA 7.3) */
+  if (qdd) {
+    V6 a_prev = {0, 0, 0, 0, 0, -ep->gravity_z};
+    for (int i = 0; i < n; ++i) {
+      V6 ap; m6_vec(X[i], a_prev, ap);
+      for (int k = 0; k < 6; ++k) ap[k] += c[i][k];
+      qdd[i] = (u[i] - dot6(U[i], ap)) / D[i];
+      for (int k = 0; k < 6; ++k) a_prev[k] = ap[k] + S[i][k] * qdd[i];
+    }
+  }
+  /* unit-torque responses with the same factorisation: column k of the inverse */
+  if (minv) {
+    for (int k = 0; k < n; ++k) {
+      double uk[OS2R_MAX_DOF]; V6 p = {0};
+      for (int i = n - 1; i >= 0; --i) {
+        uk[i] = (i == k ? 1.0 : 0.0) - dot6(S[i], p);
+        if (i > 0) { V6 pa, t; for (int r = 0; r < 6; ++r) pa[r] = p[r] + U[i][r] * uk[i] / D[i];
+                     m6t_vec(X[i], pa, t); memcpy(p, t, sizeof(V6)); }
+      }
+      V6 a_prev = {0};
+      for (int i = 0; i < n; ++i) {
+        V6 ap; m6_vec(X[i], a_prev, ap);
+        double x = (uk[i] - dot6(U[i], ap)) / D[i];
+        minv[i * n + k] = x;
+        for (int r = 0; r < 6; ++r) a_prev[r] = ap[r] + S[i][r] * x;
+      }
+    }
+  }
+}
+
+void orc_dynamics(const Os2rModel* md, double dt, const double* mass_scale, const double* damping,
+                  double gravity_z, const double* q, const double* qd, const double* tau_full,
+                  double* qdd, double* minv, double* rw, double* ow) {
+  EnvParams ep; nominal_params(md, &ep);
+  if (mass_scale) memcpy(ep.mass_scale, mass_scale, md->nq * sizeof(double));
+  if (damping) memcpy(ep.damping, damping, md->nq * sizeof(double));
+  ep.gravity_z = gravity_z;
+  dynamics(md, &ep, dt, q, qd, tau_full, qdd, minv, (double(*)[9])rw, (double(*)[3])ow);
+}
+
+/* ------------------------------------------------------------------------- *
+ * One physics iteration (the work of one `gazebo.run()`, gazebo_runtime.py:76).
+ * ------------------------------------------------------------------------- */
+typedef struct { double J[OS2R_MAX_DOF], T[OS2R_MAX_DOF], d, target, lambda; int kind, normal_row; double bound; } Row;
+/* kind: 0 normal (lambda>=0), 1 tangential (|lambda|<=mu*lambda_normal), 2 joint friction (|lambda|<=bound) */
+
+void orc_contact_points(const Os2rModel* md, const double (*rw)[9], const double (*ow)[3],
+                        int* active, double (*pw)[3], double* depth) {
+  int k = 0;
+  for (int b = 0; b < md->nq; ++b) {
+    double W = 0, pl[3] = {0, 0, 0};
+    active[b] = 0;
+    for (; k < md->ncand && md->cand_body[k] == b; ++k) {
+      const double* p = md->cand_p[k];
+      double z = rw[b][6] * p[0] + rw[b][7] * p[1] + rw[b][8] * p[2] + ow[b][2];
+      double w = z < 0.0 ? -z : 0.0;
+      W += w; pl[0] += w * p[0]; pl[1] += w * p[1]; pl[2] += w * p[2];
+    }
+    if (W > 0.0) {
+      double pc[3] = {pl[0] / W, pl[1] / W, pl[2] / W}, t[3];
+      m3_vec(rw[b], pc, t);
+      for (int i = 0; i < 3; ++i) pw[b][i] = t[i] + ow[b][i];
+      depth[b] = -pw[b][2];
+      active[b] = 1;
+    }
+  }
+}
+
+static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
+  const Os2rModel* md = &cfg->model;
+  const int n = md->nq;
+  const double dt = cfg->dt;
+  double tau[OS2R_MAX_DOF] = {0}, qdd[OS2R_MAX_DOF], minv[OS2R_MAX_DOF * OS2R_MAX_DOF];
+  double rw[OS2R_MAX_DOF][9], ow[OS2R_MAX_DOF][3];
+  tau[md->act_dof[0]] = tau2[0];
+  tau[md->act_dof[1]] = tau2[1];
+  dynamics(md, ep, dt, q, qd, tau, qdd, minv, rw, ow);
+
+  double v[OS2R_MAX_DOF];
+  for (int i = 0; i < n; ++i) v[i] = qd[i] + dt * qdd[i];
+
+  Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+  int nr = 0;
+  if (cfg->contact) {
+    int active[OS2R_MAX_DOF]; double pw[OS2R_MAX_DOF][3], depth[OS2R_MAX_DOF];
+    orc_contact_points(md, rw, ow, active, pw, depth);
+    for (int b = 0; b < n; ++b) {
+      if (!active[b]) continue;
+      double Jp[3][OS2R_MAX_DOF];
+      for (int j = 0; j < n; ++j) {
+        if (j <= b) {
+          double aw[3] = {rw[j][md->axis[j]], rw[j][3 + md->axis[j]], rw[j][6 + md->axis[j]]};
+          double dlt[3] = {pw[b][0] - ow[j][0], pw[b][1] - ow[j][1], pw[b][2] - ow[j][2]}, cr[3];
+          cross3(aw, dlt, cr);
+          Jp[0][j] = cr[0]; Jp[1][j] = cr[1]; Jp[2][j] = cr[2];
+        } else { Jp[0][j] = Jp[1][j] = Jp[2][j] = 0.0; }
+      }
+      double erv = cfg->erp * depth[b] / dt;
+      if (erv > cfg->max_erv) erv = cfg->max_erv;
+      const int dirs[3] = {2, 0, 1};  /* normal z, then tangents x, y */
+      int nrow = nr;
+      for (int t = 0; t < 3; ++t) {
+        Row* r = &rows[nr++];
+        memset(r, 0, sizeof(Row));
+        for (int j = 0; j < n; ++j) r->J[j] = Jp[dirs[t]][j];
+        r->kind = t == 0 ? 0 : 1; r->normal_row = nrow; r->bound = ep->mu[b];
+        r->target = t == 0 ? erv : 0.0;
+      }
+    }
+  }
+  for (int j = 0; j < n; ++j) {
+    if (!(ep->friction[j] > 0.0)) continue;
+    Row* r = &rows[nr++];
+    memset(r, 0, sizeof(Row));
+    r->J[j] = 1.0; r->kind = 2; r->bound = ep->friction[j] * dt; r->target = 0.0;
+  }
+  for (int r = 0; r < nr; ++r) {
+    Row* R = &rows[r];
+    for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += minv[i * n + j] * R->J[j]; R->T[i] = s; }
+    double s = 0; for (int j = 0; j < n; ++j) s += R->J[j] * R->T[j];
+    R->d = s;
+  }
+  /* projected Gauss-Seidel on the velocities, fixed sweep count, cold start */
+  for (int it = 0; it < cfg->pgs_iters; ++it) {
+    for (int r = 0; r < nr; ++r) {
+      Row* R = &rows[r];
+      if (!(R->d > 0.0)) continue;
+      double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
+      double lam = R->lambda - res / R->d, lo, hi;
+      if (R->kind == 0) { lo = 0.0; hi = INFINITY; }
+      else if (R->kind == 1) { hi = R->bound * rows[R->normal_row].lambda; lo = -hi; }
+      else { hi = R->bound; lo = -hi; }
+      if (lam < lo) lam = lo;
+      if (lam > hi) lam = hi;
+      double dl = lam - R->lambda;
+      R->lambda = lam;
+      for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
+    }
+  }
+  for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += dt * v[i]; }
+}
+
+void orc_substep(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
+                 const double* mu, double gravity_z, double* q, double* qd, const double tau2[2]) {
+  EnvParams ep; nominal_params(&cfg->model, &ep);
+  int n = cfg->model.nq;
+  if (mass_scale) memcpy(ep.mass_scale, mass_scale, n * sizeof(double));
+  if (damping) memcpy(ep.damping, damping, n * sizeof(double));
+  if (friction) memcpy(ep.friction, friction, n * sizeof(double));
+  if (mu) memcpy(ep.mu, mu, n * sizeof(double));
+  ep.gravity_z = gravity_z;
+  substep(cfg, &ep, q, qd, tau2);
+}
+
+/* ------------------------------------------------------------------------- *
+ * Batched simulator with the same semantics as the C-ABI in include/os2r.h.
+ * Host arrays, SoA [count][N] like the device layout.
+ * ------------------------------------------------------------------------- */
+struct OrcSim {
+  Os2rConfig cfg;
+  int64_t N;
+  double *q, *qd;          /* [nq][N] */
+  double *hist;            /* [2][2][N]: hist[which][j][e] */
+  double *mass_scale, *damping, *friction, *mu, *gravity; /* [nq][N] ..., [N] */
+  int32_t* steps; uint32_t* episode; uint8_t* pose;
+  uint64_t step_count;
+  int nthreads;
+};
+
+static void load_params(const OrcSim* s, int64_t e, EnvParams* ep) {
+  int n = s->cfg.model.nq; int64_t N = s->N;
+  for (int i = 0; i < n; ++i) {
+    ep->mass_scale[i] = s->mass_scale[i * N + e]; ep->damping[i] = s->damping[i * N + e];
+    ep->friction[i] = s->friction[i * N + e]; ep->mu[i] = s->mu[i * N + e];
+  }
+  ep->gravity_z = s->gravity[e];
+}
+
+/* randomizers/monopod_no_rand.py:59-98 and randomizers/monopod.py:89-128,182-215 */
+static void reset_env(OrcSim* s, int64_t e) {
+  const Os2rConfig* cfg = &s->cfg; const Os2rTaskSpec* ts = &cfg->task;
+  const int n = cfg->model.nq; const int64_t N = s->N;
+  const uint32_t genv = (uint32_t)(cfg->env_offset + e);
+  const uint32_t epi = s->episode[e];
+  double u[2], qn[OS2R_MAX_DOF] = {0};
+  orc_uniform2(cfg->seed, genv, STREAM_RESET, epi, 0, u);
+  int pi = (int)(u[0] * ts->n_reset_poses);
+  if (pi >= ts->n_reset_poses) pi = ts->n_reset_poses - 1;
+  double pitch = ts->reset_pitch[pi], hip, knee, yaw = 0.0;
+  if (ts->reset_mode == OS2R_RESET_FIXED) {
+    if (ts->reset_simple) {
+      /* observation_space.sample() of the two joint angles: U(-1,1) (monopod_no_rand.py:84) */
+      double w[2]; orc_uniform2(cfg->seed, genv, STREAM_RESET, epi, 1, w);
+      hip = 2.0 * w[0] - 1.0; knee = 2.0 * w[1] - 1.0;
+    } else { hip = ts->reset_hip[pi]; knee = ts->reset_knee[pi]; }
+  } else {
+    pitch *= 0.8 + 0.4 * u[1];                                   /* monopod.py:94 */
+    double z[2], w[2], w2[2];
+    normal2(cfg->seed, genv, STREAM_RESET, epi, 1, z);
+    orc_uniform2(cfg->seed, genv, STREAM_RESET, epi, 2, w);
+    orc_uniform2(cfg->seed, genv, STREAM_RESET, epi, 3, w2);
+    double r0 = fabs(0.2 * z[0]), r1 = fabs(0.2 * z[1]);
+    double rmax = r0 > r1 ? r0 : r1, rmin = r0 > r1 ? r1 : r0;
+    if (!ts->reset_laying[pi]) { double a[2]; orc_leg_joint_angles(ts->leg_def, pitch, a); hip = a[0]; knee = a[1]; }
+    else { hip = 1.57 - (w[0] < 0.5 ? 3.14 : 0.0); knee = 0.0; }      /* :106 */
+    /* `(x>0 - x<0)` is the chained comparison x>0 (monopod.py:102-103,109-110) */
+    hip = hip + (hip > 0.0 ? 1.0 : 0.0) * rmax;
+    knee = knee - (knee > 0.0 ? 1.0 : 0.0) * rmin;
+    double dir = 1.0 - (w[1] < 0.5 ? 2.0 : 0.0);                  /* :111 */
+    hip *= dir; knee *= dir;
+    yaw = -0.2 + 0.4 * w2[0];                                     /* :113 */
+  }
+  if (ts->dof_pitch >= 0) qn[ts->dof_pitch] = pitch;
+  if (ts->dof_yaw >= 0) qn[ts->dof_yaw] = yaw;
+  if (ts->dof_hip >= 0) qn[ts->dof_hip] = hip;
+  if (ts->dof_knee >= 0) qn[ts->dof_knee] = knee;
+  for (int i = 0; i < n; ++i) { s->q[i * N + e] = qn[i]; s->qd[i * N + e] = 0.0; }
+  s->pose[e] = (uint8_t)ts->reset_pose_id[pi];
+  s->steps[e] = 0;
+  if (ts->reset_mode == OS2R_RESET_RANDOM && ts->randomize_params) {
+    const Os2rModel* md = &cfg->model;
+    for (int i = 0; i < n; ++i) {
+      double a[2], b[2];
+      orc_uniform2(cfg->seed, genv, STREAM_PARAMS, epi, 2 * i, a);
+      orc_uniform2(cfg->seed, genv, STREAM_PARAMS, epi, 2 * i + 1, b);
+      s->mass_scale[i * N + e] = ts->dr_mass_lo + (ts->dr_mass_hi - ts->dr_mass_lo) * a[0];
+      s->friction[i * N + e] = ts->dr_friction_lo + (ts->dr_friction_hi - ts->dr_friction_lo) * a[1];
+      s->damping[i * N + e] = md->damping[i] * (ts->dr_damping_lo + (ts->dr_damping_hi - ts->dr_damping_lo) * b[0]);
+      s->mu[i * N + e] = ts->dr_mu_base * (ts->dr_mu_lo + (ts->dr_mu_hi - ts->dr_mu_lo) * b[1]);
+    }
+  }
+  s->episode[e] = epi + 1;
+}
+
+int orc_create(const Os2rConfig* cfg, OrcSim** out) {
+  if (!cfg || !out || cfg->abi_version != OS2R_ABI_VERSION || cfg->num_envs <= 0) return OS2R_ERR_INVALID;
+  OrcSim* s = (OrcSim*)calloc(1, sizeof(OrcSim));
+  s->cfg = *cfg; s->N = cfg->num_envs; s->nthreads = 1;
+  const int n = cfg->model.nq; const int64_t N = s->N;
+  s->q = calloc(n * N, 8); s->qd = calloc(n * N, 8); s->hist = calloc(4 * N, 8);
+  s->mass_scale = calloc(n * N, 8); s->damping = calloc(n * N, 8); s->friction = calloc(n * N, 8);
+  s->mu = calloc(n * N, 8); s->gravity = calloc(N, 8);
+  s->steps = calloc(N, 4); s->episode = calloc(N, 4); s->pose = calloc(N, 1);
+  for (int64_t e = 0; e < N; ++e) {
+    for (int i = 0; i < n; ++i) {
+      s->mass_scale[i * N + e] = 1.0; s->damping[i * N + e] = cfg->model.damping[i];
+      s->friction[i * N + e] = cfg->model.friction[i]; s->mu[i * N + e] = cfg->model.mu[i];
+    }
+    s->gravity[e] = cfg->model.gravity_z;
+    if (cfg->task.reset_mode == OS2R_RESET_RANDOM && cfg->task.dr_gravity_std > 0.0) {
+      double z[2]; normal2(cfg->seed, (uint32_t)(cfg->env_offset + e), STREAM_GRAVITY, 0, 0, z);
+      s->gravity[e] = cfg->task.dr_gravity_mean + cfg->task.dr_gravity_std * z[0];   /* monopod.py:58 */
+    }
+    reset_env(s, e);
+  }
+  *out = s;
+  return OS2R_OK;
+}
+
+void orc_destroy(OrcSim* s) {
+  if (!s) return;
+  free(s->q); free(s->qd); free(s->hist); free(s->mass_scale); free(s->damping); free(s->friction);
+  free(s->mu); free(s->gravity); free(s->steps); free(s->episode); free(s->pose); free(s);
+}
+
+void orc_set_threads(OrcSim* s, int n) { s->nthreads = n < 1 ? 1 : n; }
+
+static void observe_env(const OrcSim* s, int64_t e, double* obs) {
+  const int n = s->cfg.model.nq; const int64_t N = s->N;
+  double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF], h1[2];
+  for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
+  h1[0] = s->hist[(2 + 0) * N + e]; h1[1] = s->hist[(2 + 1) * N + e];
+  orc_observe(&s->cfg.task, q, qd, h1, obs);
+}
+
+int orc_reset(OrcSim* s, const uint8_t* mask, double* obs) {
+  const int D = s->cfg.task.obs_dim;
+  for (int64_t e = 0; e < s->N; ++e) {
+    if (!mask || mask[e]) reset_env(s, e);
+    if (obs) observe_env(s, e, obs + e * D);
+  }
+  return OS2R_OK;
+}
+
+int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint8_t* done, double* term_obs) {
+  const Os2rConfig* cfg = &s->cfg; const Os2rTaskSpec* ts = &cfg->task;
+  const int n = cfg->model.nq, D = ts->obs_dim; const int64_t N = s->N;
+  const uint64_t t = s->step_count;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(s->nthreads) schedule(static)
+#endif
+  for (int64_t e = 0; e < N; ++e) {
+    double a[2];
+    if (actions) { a[0] = actions[2 * e]; a[1] = actions[2 * e + 1]; }
+    else {
+      double u[2]; orc_uniform2(cfg->seed, (uint32_t)(cfg->env_offset + e), STREAM_ACTION, (uint32_t)t, (uint32_t)(t >> 32), u);
+      a[0] = 2.0 * u[0] - 1.0; a[1] = 2.0 * u[1] - 1.0;
+    }
+    for (int j = 0; j < 2; ++j) { if (a[j] < -1.0) a[j] = -1.0; if (a[j] > 1.0) a[j] = 1.0; }
+    double tau[2] = {cfg->model.max_torque[0] * a[0], cfg->model.max_torque[1] * a[1]};  /* monopod.py:223 */
+    double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
+    EnvParams ep; load_params(s, e, &ep);
+    for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
+    for (int k = 0; k < cfg->substeps; ++k) substep(cfg, &ep, q, qd, tau);      /* gazebo_runtime.py:70-77 */
+    int bad = 0;
+    for (int i = 0; i < n; ++i) { if (!isfinite(q[i]) || !isfinite(qd[i])) bad = 1; s->q[i * N + e] = q[i]; s->qd[i * N + e] = qd[i]; }
+    /* action_history.appendleft (monopod.py:232-235) */
+    double h1[2] = {s->hist[0 * N + e], s->hist[1 * N + e]};
+    s->hist[2 * N + e] = h1[0]; s->hist[3 * N + e] = h1[1];
+    /* the history stores the read-back force target divided by max_torque: (2.5*a)/2.5 */
+    double as[2] = {tau[0] / cfg->model.max_torque[0], tau[1] / cfg->model.max_torque[1]};
+    s->hist[0 * N + e] = as[0]; s->hist[1 * N + e] = as[1];
+    double ob[OS2R_MAX_OBS];
+    orc_observe(ts, q, qd, h1, ob);
+    double rew = orc_reward(ts, ob, as, h1);
+    int dn = orc_done(ts, ob);
+    s->steps[e] += 1;
+    int trunc = ts->max_episode_steps > 0 && s->steps[e] >= ts->max_episode_steps;
+    uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
+    if (term_obs) memcpy(term_obs + e * D, ob, D * sizeof(double));
+    if (flag && cfg->auto_reset) { reset_env(s, e); observe_env(s, e, ob); }    /* subproc_vec_env.py:17-20 */
+    if (obs) memcpy(obs + e * D, ob, D * sizeof(double));
+    if (reward) reward[e] = rew;
+    if (done) done[e] = flag;
+  }
+  s->step_count = t + 1;
+  return OS2R_OK;
+}
+
+int orc_get_state(OrcSim* s, double* q, double* qd) {
+  size_t b = (size_t)s->cfg.model.nq * s->N * 8;
+  if (q) memcpy(q, s->q, b);
+  if (qd) memcpy(qd, s->qd, b);
+  return OS2R_OK;
+}
+int orc_set_state(OrcSim* s, const double* q, const double* qd) {
+  size_t b = (size_t)s->cfg.model.nq * s->N * 8;
+  if (q) memcpy(s->q, q, b);
+  if (qd) memcpy(s->qd, qd, b);
+  return OS2R_OK;
+}
+int orc_get_action_history(OrcSim* s, int which, double* out) { memcpy(out, s->hist + (size_t)which * 2 * s->N, 2 * s->N * 8); return OS2R_OK; }
+int orc_set_action_history(OrcSim* s, int which, const double* in) { memcpy(s->hist + (size_t)which * 2 * s->N, in, 2 * s->N * 8); return OS2R_OK; }
+
+static double* param_ptr(OrcSim* s, int field, int* count) {
+  int n = s->cfg.model.nq;
+  switch (field) {
+    case OS2R_PARAM_MASS_SCALE: *count = n; return s->mass_scale;
+    case OS2R_PARAM_DAMPING: *count = n; return s->damping;
+    case OS2R_PARAM_FRICTION: *count = n; return s->friction;
+    case OS2R_PARAM_MU: *count = n; return s->mu;
+    case OS2R_PARAM_GRAVITY: *count = 1; return s->gravity;
+    default: *count = 0; return NULL;
+  }
+}
+int orc_set_params(OrcSim* s, int field, const double* src) {
+  int c; double* p = param_ptr(s, field, &c); if (!p) return OS2R_ERR_INVALID;
+  memcpy(p, src, (size_t)c * s->N * 8); return OS2R_OK;
+}
+int orc_get_params(OrcSim* s, int field, double* dst) {
+  int c; double* p = param_ptr(s, field, &c); if (!p) return OS2R_ERR_INVALID;
+  memcpy(dst, p, (size_t)c * s->N * 8); return OS2R_OK;
+}
+int orc_get_episode_info(OrcSim* s, int32_t* steps, uint32_t* episode, uint8_t* pose) {
+  if (steps) memcpy(steps, s->steps, s->N * 4);
+  if (episode) memcpy(episode, s->episode, s->N * 4);
+  if (pose) memcpy(pose, s->pose, s->N);
+  return OS2R_OK;
+}
+uint64_t orc_get_step_count(OrcSim* s) { return s->step_count; }
+void orc_set_step_count(OrcSim* s, uint64_t v) { s->step_count = v; }

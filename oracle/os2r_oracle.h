@@ -1,0 +1,54 @@
+/* os2r_oracle.h — CPU restatement of the gym-os2r env-step path (TEST INFRASTRUCTURE ONLY;
+ * see the header of os2r_oracle.c).  Host pointers everywhere, fp64 only. */
+#ifndef OS2R_ORACLE_H_
+#define OS2R_ORACLE_H_
+#include <stdint.h>
+#include "../include/os2r.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcSim OrcSim;
+
+/* counter RNG */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_uniform2(uint64_t seed, uint32_t env, uint32_t stream, uint32_t ctr, uint32_t blk, double u[2]);
+
+/* task-level pieces (pinned by tests/golden/) */
+double orc_tolerance(double x, double lower, double upper, double margin, int sigmoid, double value_at_margin);
+void orc_leg_joint_angles(const double def6[6], double pitch, double out[2]);
+double orc_wrap(double x);
+void orc_observe(const Os2rTaskSpec* ts, const double* q, const double* qd, const double hist1[2], double* obs);
+int orc_done(const Os2rTaskSpec* ts, const double* obs);
+double orc_reward(const Os2rTaskSpec* ts, const double* obs, const double a0[2], const double a1[2]);
+
+/* dynamics of one environment (parity unpinned; checked by known answers + invariants) */
+void orc_dynamics(const Os2rModel* md, double dt, const double* mass_scale, const double* damping,
+                  double gravity_z, const double* q, const double* qd, const double* tau_full,
+                  double* qdd, double* minv, double* rw, double* ow);
+void orc_contact_points(const Os2rModel* md, const double (*rw)[9], const double (*ow)[3],
+                        int* active, double (*pw)[3], double* depth);
+void orc_substep(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
+                 const double* mu, double gravity_z, double* q, double* qd, const double tau2[2]);
+
+/* batched simulator mirroring include/os2r.h on host arrays */
+int orc_create(const Os2rConfig* cfg, OrcSim** out);
+void orc_destroy(OrcSim* s);
+void orc_set_threads(OrcSim* s, int n);
+int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);
+int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint8_t* done, double* term_obs);
+int orc_get_state(OrcSim* s, double* q, double* qd);
+int orc_set_state(OrcSim* s, const double* q, const double* qd);
+int orc_get_action_history(OrcSim* s, int which, double* out);
+int orc_set_action_history(OrcSim* s, int which, const double* in);
+int orc_set_params(OrcSim* s, int field, const double* src);
+int orc_get_params(OrcSim* s, int field, double* dst);
+int orc_get_episode_info(OrcSim* s, int32_t* steps, uint32_t* episode, uint8_t* pose);
+uint64_t orc_get_step_count(OrcSim* s);
+void orc_set_step_count(OrcSim* s, uint64_t v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
