@@ -1,0 +1,426 @@
+// os2r_capi.hip — implementation of the C-ABI declared in include/os2r.h.
+//
+// Host-side only: owns the device buffers of one simulator handle, converts the
+// host config into the uniform device structs, and launches the kernels of
+// os2r_kernels.hpp on the caller's stream.  Nothing here computes physics on the
+// CPU; a missing GPU is an error (OS2R_ERR_NO_DEVICE), never a fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "os2r_kernels.hpp"
+
+using namespace os2r;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct SimBase {
+  Os2rConfig cfg;
+  std::string err;
+  int nq = 0, D = 0;
+  unsigned cmask = 0;
+  bool dr = false;
+  size_t esz = 8;
+  unsigned long long step_count = 0;
+  std::vector<void*> allocs;
+  // device buffers (typed views below)
+  void *model_d = nullptr, *task_d = nullptr;
+  void *q = nullptr, *qd = nullptr, *hist = nullptr;
+  void *mass_scale = nullptr, *damping = nullptr, *friction = nullptr, *mu = nullptr, *gravity = nullptr;
+  int32_t* steps = nullptr;
+  uint32_t* episode = nullptr;
+  uint8_t* pose = nullptr;
+  // scratch outputs for os2r_bench_steps
+  void *b_obs = nullptr, *b_rew = nullptr;
+  uint8_t* b_done = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+}  // namespace
+
+struct Os2rSim : SimBase {};
+
+namespace {
+
+#define HIP_TRY(sim, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      (sim)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+      return OS2R_ERR_HIP;                                                                     \
+    }                                                                                          \
+  } while (0)
+
+template <typename T>
+void fill_model(const Os2rModel& m, DevModel<T>& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.nq = m.nq;
+  for (int i = 0; i < OS2R_MAX_DOF; ++i) {
+    d.axis[i] = m.axis[i];
+    for (int k = 0; k < 9; ++k) d.rfix[i][k] = (T)m.rfix[i][k];
+    for (int k = 0; k < 3; ++k) { d.rpos[i][k] = (T)m.rpos[i][k]; d.com[i][k] = (T)m.com[i][k]; }
+    for (int k = 0; k < 6; ++k) d.icom[i][k] = (T)m.icom[i][k];
+    d.mass[i] = (T)m.mass[i];
+    d.damping[i] = (T)m.damping[i];
+    d.friction[i] = (T)m.friction[i];
+    d.mu[i] = (T)m.mu[i];
+  }
+  for (int k = 0; k < 2; ++k) { d.act_dof[k] = m.act_dof[k]; d.max_torque[k] = (T)m.max_torque[k]; }
+  d.gravity_z = (T)m.gravity_z;
+  int k = 0;
+  for (int b = 0; b < OS2R_MAX_DOF; ++b) {
+    d.cand_begin[b] = k;
+    while (k < m.ncand && m.cand_body[k] == b) ++k;
+  }
+  d.cand_begin[OS2R_MAX_DOF] = k;
+  for (int c = 0; c < m.ncand; ++c)
+    for (int j = 0; j < 3; ++j) d.cand_p[c][j] = (T)m.cand_p[c][j];
+}
+
+template <typename T>
+void fill_task(const Os2rConfig& cfg, DevTask<T>& d) {
+  const Os2rTaskSpec& t = cfg.task;
+  std::memset(&d, 0, sizeof(d));
+  d.obs_dim = t.obs_dim;
+  for (int i = 0; i < OS2R_MAX_OBS; ++i) {
+    d.obs_kind[i] = t.obs_kind[i];
+    d.obs_src[i] = t.obs_src[i];
+    d.obs_low[i] = (T)t.obs_low[i];
+    d.obs_high[i] = (T)t.obs_high[i];
+    d.done_lo[i] = (T)t.done_lo[i];
+    d.done_hi[i] = (T)t.done_hi[i];
+  }
+  d.reward_id = t.reward_id; d.normalized = t.normalized;
+  d.idx_pitch_pos = t.idx_pitch_pos; d.idx_yaw_vel = t.idx_yaw_vel;
+  d.idx_hip_pos = t.idx_hip_pos; d.idx_knee_pos = t.idx_knee_pos;
+  d.max_episode_steps = t.max_episode_steps;
+  d.reset_mode = t.reset_mode; d.n_reset_poses = t.n_reset_poses;
+  for (int i = 0; i < OS2R_MAX_RESET_POSES; ++i) {
+    d.reset_pose_id[i] = t.reset_pose_id[i]; d.reset_laying[i] = t.reset_laying[i];
+    d.reset_pitch[i] = t.reset_pitch[i]; d.reset_hip[i] = t.reset_hip[i]; d.reset_knee[i] = t.reset_knee[i];
+  }
+  d.reset_simple = t.reset_simple;
+  for (int i = 0; i < 6; ++i) d.leg_def[i] = t.leg_def[i];
+  d.dof_yaw = t.dof_yaw; d.dof_pitch = t.dof_pitch; d.dof_bc = t.dof_bc; d.dof_hip = t.dof_hip; d.dof_knee = t.dof_knee;
+  d.randomize_params = t.randomize_params;
+  d.dr_mass_lo = t.dr_mass_lo; d.dr_mass_hi = t.dr_mass_hi;
+  d.dr_friction_lo = t.dr_friction_lo; d.dr_friction_hi = t.dr_friction_hi;
+  d.dr_damping_lo = t.dr_damping_lo; d.dr_damping_hi = t.dr_damping_hi;
+  d.dr_mu_base = t.dr_mu_base; d.dr_mu_lo = t.dr_mu_lo; d.dr_mu_hi = t.dr_mu_hi;
+  for (int i = 0; i < OS2R_MAX_DOF; ++i) d.nominal_damping[i] = cfg.model.damping[i];
+}
+
+int validate(const Os2rConfig* c, std::string& why) {
+  if (!c) { why = "null config"; return 1; }
+  if (c->abi_version != OS2R_ABI_VERSION) { why = "abi_version mismatch"; return 1; }
+  if (c->dtype != OS2R_F32 && c->dtype != OS2R_F64) { why = "dtype must be OS2R_F32 or OS2R_F64"; return 1; }
+  if (c->num_envs <= 0) { why = "num_envs must be positive"; return 1; }
+  const Os2rModel& m = c->model;
+  if (m.nq < 2 || m.nq > OS2R_MAX_DOF) { why = "model.nq must be 2..5"; return 1; }
+  if (m.ncand < 0 || m.ncand > OS2R_MAX_CAND) { why = "model.ncand out of range"; return 1; }
+  int last = 0;
+  for (int k = 0; k < m.ncand; ++k) {
+    if (m.cand_body[k] < last || m.cand_body[k] >= m.nq) { why = "cand_body must be non-decreasing and < nq"; return 1; }
+    last = m.cand_body[k];
+  }
+  for (int i = 0; i < m.nq; ++i) {
+    if (m.axis[i] < 0 || m.axis[i] > 2) { why = "joint axis must be 0,1,2"; return 1; }
+    if (!(m.mass[i] > 0.0)) { why = "body mass must be positive"; return 1; }
+  }
+  for (int k = 0; k < 2; ++k)
+    if (m.act_dof[k] < 0 || m.act_dof[k] >= m.nq) { why = "act_dof out of range"; return 1; }
+  const Os2rTaskSpec& t = c->task;
+  if (t.obs_dim < 1 || t.obs_dim > OS2R_MAX_OBS) { why = "task.obs_dim out of range"; return 1; }
+  for (int d = 0; d < t.obs_dim; ++d) {
+    const int kind = t.obs_kind[d];
+    if (kind < OS2R_OBS_POS_NORM || kind > OS2R_OBS_TORQUE_RAW) { why = "unknown obs kind"; return 1; }
+    const bool tq = kind == OS2R_OBS_TORQUE_NORM || kind == OS2R_OBS_TORQUE_RAW;
+    if (t.obs_src[d] < 0 || t.obs_src[d] >= (tq ? 2 : m.nq)) { why = "obs_src out of range"; return 1; }
+  }
+  if (t.reward_id < 0 || t.reward_id > OS2R_REWARD_STRAIGHT_V1) { why = "unknown reward id"; return 1; }
+  if (t.reward_id != OS2R_REWARD_STRAIGHT_V1 && t.idx_pitch_pos < 0) { why = "reward needs the pitch position observed"; return 1; }
+  if (t.reward_id == OS2R_REWARD_HOPPING_V1 && t.idx_yaw_vel < 0) { why = "HoppingV1 needs the yaw velocity observed"; return 1; }
+  if (t.reward_id == OS2R_REWARD_STRAIGHT_V1 && (t.idx_hip_pos < 0 || t.idx_knee_pos < 0)) { why = "StraightV1 needs hip and knee positions"; return 1; }
+  if (t.n_reset_poses < 1 || t.n_reset_poses > OS2R_MAX_RESET_POSES) { why = "n_reset_poses out of range"; return 1; }
+  if (c->substeps < 1 || c->substeps > 1000) { why = "substeps out of range"; return 1; }
+  if (!(c->dt > 0.0)) { why = "dt must be positive"; return 1; }
+  if (c->pgs_iters < 0 || c->pgs_iters > 10000) { why = "pgs_iters out of range"; return 1; }
+  return 0;
+}
+
+template <typename T>
+StepArgs<T> make_args(Os2rSim* s) {
+  StepArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.model = (const DevModel<T>*)s->model_d;
+  a.task = (const DevTask<T>*)s->task_d;
+  a.N = s->cfg.num_envs;
+  a.env_offset = s->cfg.env_offset;
+  a.seed = s->cfg.seed;
+  a.step_count = s->step_count;
+  a.substeps = s->cfg.substeps;
+  a.pgs_iters = s->cfg.pgs_iters;
+  a.auto_reset = s->cfg.auto_reset;
+  a.dt = (T)s->cfg.dt; a.erp = (T)s->cfg.erp; a.max_erv = (T)s->cfg.max_erv;
+  a.q = (T*)s->q; a.qd = (T*)s->qd; a.hist = (T*)s->hist;
+  a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
+  a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
+  a.steps = s->steps; a.episode = s->episode; a.pose = s->pose;
+  return a;
+}
+
+template <typename T>
+int do_reset(Os2rSim* s, const uint8_t* mask, void* obs, hipStream_t st) {
+  StepArgs<T> a = make_args<T>(s);
+  a.reset_mask = mask;
+  a.obs = (T*)obs;
+  if (Launcher<T>::reset(s->nq, s->dr, a, st) != 0) { s->err = "no reset kernel for this chain length"; return OS2R_ERR_INVALID; }
+  HIP_TRY(s, hipGetLastError());
+  return OS2R_OK;
+}
+
+template <typename T>
+int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* done, void* term, hipStream_t st) {
+  StepArgs<T> a = make_args<T>(s);
+  a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
+  if (Launcher<T>::step(s->nq, s->cmask, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
+  HIP_TRY(s, hipGetLastError());
+  s->step_count += 1;
+  return OS2R_OK;
+}
+
+template <typename T>
+int init_params(Os2rSim* s, hipStream_t st) {
+  const long long N = s->cfg.num_envs;
+  for (int i = 0; i < s->nq; ++i) {
+    Launcher<T>::fill((T*)s->mass_scale + i * N, N, T(1), st);
+    Launcher<T>::fill((T*)s->damping + i * N, N, (T)s->cfg.model.damping[i], st);
+    Launcher<T>::fill((T*)s->friction + i * N, N, (T)s->cfg.model.friction[i], st);
+    Launcher<T>::fill((T*)s->mu + i * N, N, (T)s->cfg.model.mu[i], st);
+  }
+  if (s->cfg.task.reset_mode == OS2R_RESET_RANDOM && s->cfg.task.dr_gravity_std > 0.0)
+    Launcher<T>::gravity((T*)s->gravity, N, s->cfg.env_offset, s->cfg.seed, s->cfg.task.dr_gravity_mean,
+                         s->cfg.task.dr_gravity_std, st);
+  else
+    Launcher<T>::fill((T*)s->gravity, N, (T)s->cfg.model.gravity_z, st);
+  HIP_TRY(s, hipGetLastError());
+  return OS2R_OK;
+}
+
+int dev_alloc(Os2rSim* s, void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) { s->err = std::string("hipMalloc: ") + hipGetErrorString(e); return OS2R_ERR_ALLOC; }
+  s->allocs.push_back(*p);
+  e = hipMemset(*p, 0, bytes);
+  if (e != hipSuccess) { s->err = std::string("hipMemset: ") + hipGetErrorString(e); return OS2R_ERR_HIP; }
+  return OS2R_OK;
+}
+
+void free_all(Os2rSim* s) {
+  for (void* p : s->allocs) (void)hipFree(p);
+  s->allocs.clear();
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+}
+
+int param_view(Os2rSim* s, int field, void** base, int* count) {
+  switch (field) {
+    case OS2R_PARAM_MASS_SCALE: *base = s->mass_scale; *count = s->nq; return 0;
+    case OS2R_PARAM_DAMPING: *base = s->damping; *count = s->nq; return 0;
+    case OS2R_PARAM_FRICTION: *base = s->friction; *count = s->nq; return 0;
+    case OS2R_PARAM_MU: *base = s->mu; *count = s->nq; return 0;
+    case OS2R_PARAM_GRAVITY: *base = s->gravity; *count = 1; return 0;
+    default: return 1;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int os2r_abi_version(void) { return OS2R_ABI_VERSION; }
+
+int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
+  if (!out) { g_create_error = "null out pointer"; return OS2R_ERR_INVALID; }
+  *out = nullptr;
+  std::string why;
+  if (validate(cfg, why)) { g_create_error = why; return OS2R_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device visible: the stepper has no CPU fallback";
+    return OS2R_ERR_NO_DEVICE;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return OS2R_ERR_INVALID; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) { g_create_error = "hipGetDeviceProperties failed"; return OS2R_ERR_HIP; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+    return OS2R_ERR_NO_DEVICE;
+  }
+  Os2rSim* s = new (std::nothrow) Os2rSim();
+  if (!s) { g_create_error = "out of host memory"; return OS2R_ERR_ALLOC; }
+  s->cfg = *cfg;
+  s->nq = cfg->model.nq;
+  s->D = cfg->task.obs_dim;
+  s->esz = cfg->dtype == OS2R_F64 ? 8 : 4;
+  // parameter arrays are read per lane only when something can make them differ per env:
+  // the randomising reset mode, or a later os2r_set_params (which flips this on)
+  s->dr = cfg->task.reset_mode == OS2R_RESET_RANDOM;
+  s->cmask = 0;
+  if (cfg->contact)
+    for (int k = 0; k < cfg->model.ncand; ++k) s->cmask |= 1u << cfg->model.cand_body[k];
+  int rc = OS2R_OK;
+  auto fail = [&](int code) { g_create_error = s->err; free_all(s); delete s; return code; };
+  if (hipSetDevice(cfg->device) != hipSuccess) { s->err = "hipSetDevice failed"; return fail(OS2R_ERR_HIP); }
+  const size_t N = (size_t)cfg->num_envs, n = (size_t)s->nq, e = s->esz;
+  if ((rc = dev_alloc(s, &s->q, n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->qd, n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->hist, 4 * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->mass_scale, n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->damping, n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->friction, n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->mu, n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->gravity, N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, (void**)&s->steps, N * 4))) return fail(rc);
+  if ((rc = dev_alloc(s, (void**)&s->episode, N * 4))) return fail(rc);
+  if ((rc = dev_alloc(s, (void**)&s->pose, N))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->b_obs, (size_t)s->D * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->b_rew, N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, (void**)&s->b_done, N))) return fail(rc);
+  if (cfg->dtype == OS2R_F64) {
+    DevModel<double> hm; DevTask<double> ht;
+    fill_model(cfg->model, hm); fill_task(*cfg, ht);
+    if ((rc = dev_alloc(s, &s->model_d, sizeof(hm)))) return fail(rc);
+    if ((rc = dev_alloc(s, &s->task_d, sizeof(ht)))) return fail(rc);
+    if (hipMemcpy(s->model_d, &hm, sizeof(hm), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->task_d, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess) { s->err = "model upload failed"; return fail(OS2R_ERR_HIP); }
+  } else {
+    DevModel<float> hm; DevTask<float> ht;
+    fill_model(cfg->model, hm); fill_task(*cfg, ht);
+    if ((rc = dev_alloc(s, &s->model_d, sizeof(hm)))) return fail(rc);
+    if ((rc = dev_alloc(s, &s->task_d, sizeof(ht)))) return fail(rc);
+    if (hipMemcpy(s->model_d, &hm, sizeof(hm), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(s->task_d, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess) { s->err = "model upload failed"; return fail(OS2R_ERR_HIP); }
+  }
+  if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { s->err = "hipEventCreate failed"; return fail(OS2R_ERR_HIP); }
+  rc = cfg->dtype == OS2R_F64 ? init_params<double>(s, nullptr) : init_params<float>(s, nullptr);
+  if (rc) return fail(rc);
+  rc = cfg->dtype == OS2R_F64 ? do_reset<double>(s, nullptr, nullptr, nullptr) : do_reset<float>(s, nullptr, nullptr, nullptr);
+  if (rc) return fail(rc);
+  if (hipStreamSynchronize(nullptr) != hipSuccess) { s->err = "initial reset failed"; return fail(OS2R_ERR_HIP); }
+  *out = s;
+  return OS2R_OK;
+}
+
+int os2r_destroy(Os2rSim* sim) {
+  if (!sim) return OS2R_ERR_INVALID;
+  (void)hipSetDevice(sim->cfg.device);
+  (void)hipDeviceSynchronize();
+  free_all(sim);
+  delete sim;
+  return OS2R_OK;
+}
+
+int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  return sim->cfg.dtype == OS2R_F64 ? do_reset<double>(sim, mask_dev, obs_dev, (hipStream_t)stream)
+                                    : do_reset<float>(sim, mask_dev, obs_dev, (hipStream_t)stream);
+}
+
+int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev, uint8_t* done_dev,
+              void* term_obs_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  return sim->cfg.dtype == OS2R_F64
+             ? do_step<double>(sim, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, (hipStream_t)stream)
+             : do_step<float>(sim, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, (hipStream_t)stream);
+}
+
+int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  const size_t b = (size_t)sim->nq * sim->cfg.num_envs * sim->esz;
+  if (q_dev) HIP_TRY(sim, hipMemcpyAsync(q_dev, sim->q, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (qd_dev) HIP_TRY(sim, hipMemcpyAsync(qd_dev, sim->qd, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  const size_t b = (size_t)sim->nq * sim->cfg.num_envs * sim->esz;
+  if (q_dev) HIP_TRY(sim, hipMemcpyAsync(sim->q, q_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (qd_dev) HIP_TRY(sim, hipMemcpyAsync(sim->qd, qd_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_get_action_history(Os2rSim* sim, int which, void* out_dev, void* stream) {
+  if (!sim || which < 0 || which > 1 || !out_dev) return OS2R_ERR_INVALID;
+  const size_t b = 2 * (size_t)sim->cfg.num_envs * sim->esz;
+  HIP_TRY(sim, hipMemcpyAsync(out_dev, (char*)sim->hist + which * b, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_set_action_history(Os2rSim* sim, int which, const void* in_dev, void* stream) {
+  if (!sim || which < 0 || which > 1 || !in_dev) return OS2R_ERR_INVALID;
+  const size_t b = 2 * (size_t)sim->cfg.num_envs * sim->esz;
+  HIP_TRY(sim, hipMemcpyAsync((char*)sim->hist + which * b, in_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_set_params(Os2rSim* sim, int field, const void* src_dev, void* stream) {
+  void* base; int count;
+  if (!sim || !src_dev || param_view(sim, field, &base, &count)) return OS2R_ERR_INVALID;
+  HIP_TRY(sim, hipMemcpyAsync(base, src_dev, (size_t)count * sim->cfg.num_envs * sim->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  sim->dr = true;
+  return OS2R_OK;
+}
+
+int os2r_get_params(Os2rSim* sim, int field, void* dst_dev, void* stream) {
+  void* base; int count;
+  if (!sim || !dst_dev || param_view(sim, field, &base, &count)) return OS2R_ERR_INVALID;
+  HIP_TRY(sim, hipMemcpyAsync(dst_dev, base, (size_t)count * sim->cfg.num_envs * sim->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_dev, uint8_t* pose_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  const size_t N = (size_t)sim->cfg.num_envs;
+  if (steps_dev) HIP_TRY(sim, hipMemcpyAsync(steps_dev, sim->steps, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (episode_dev) HIP_TRY(sim, hipMemcpyAsync(episode_dev, sim->episode, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (pose_dev) HIP_TRY(sim, hipMemcpyAsync(pose_dev, sim->pose, N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_get_step_count(Os2rSim* sim, uint64_t* out) {
+  if (!sim || !out) return OS2R_ERR_INVALID;
+  *out = sim->step_count;
+  return OS2R_OK;
+}
+
+int os2r_set_step_count(Os2rSim* sim, uint64_t value) {
+  if (!sim) return OS2R_ERR_INVALID;
+  sim->step_count = value;
+  return OS2R_OK;
+}
+
+int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) {
+  if (!sim || nsteps < 1 || !elapsed_ms) return OS2R_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(sim, hipEventRecord(sim->ev0, st));
+  for (int k = 0; k < nsteps; ++k) {
+    int rc = os2r_step(sim, nullptr, sim->b_obs, sim->b_rew, sim->b_done, nullptr, stream);
+    if (rc) return rc;
+  }
+  HIP_TRY(sim, hipEventRecord(sim->ev1, st));
+  HIP_TRY(sim, hipEventSynchronize(sim->ev1));
+  HIP_TRY(sim, hipEventElapsedTime(elapsed_ms, sim->ev0, sim->ev1));
+  return OS2R_OK;
+}
+
+const char* os2r_last_error(Os2rSim* sim) { return sim ? sim->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,613 @@
+// os2r_device.hpp — device code of the batched monopod stepper (gfx950 / CDNA4).
+//
+// One lane integrates one environment.  State lives in HBM as struct-of-arrays
+// ([dof][env], coalesced), is held in registers across the `substeps` physics
+// iterations of one env-step, and is written back together with the
+// observation / reward / done of the same launch.  Robot constants are
+// wave-uniform: they are read through scalar loads from a read-only device
+// struct and occupy SGPRs, not per-lane registers.  No MFMA: a 5-dof serial
+// chain is not a dense contraction; the binding resource is the fp64 (or fp32)
+// vector ALU.
+//
+// What one physics iteration computes (replaces `gazebo.run()`,
+// gym_os2r/runtimes/gazebo_runtime.py:76):
+//   1. joint transforms, body velocities
+//   2. articulated-body algorithm (Featherstone) with joint damping taken
+//      implicitly in the projected articulated inertia  D_i = S'I^A S + dt*d_i
+//   3. inverse of the damping-augmented mass matrix from unit-torque sweeps over
+//      the same factorisation (upper triangle only, by symmetry)
+//   4. v* = qd + dt*qdd
+//   5. ground contact: per body, the penetration-weighted centroid of its
+//      collision candidate points gives one frictional point contact
+//   6. projected Gauss-Seidel on the velocities over [contact rows, joint
+//      Coulomb friction rows], fixed sweep count, cold start
+//   7. q += dt*v  (semi-implicit Euler)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/os2r.h"
+
+namespace os2r {
+
+constexpr int kWave = 64;
+
+// ----------------------------------------------------------------------------------------
+// uniform (per-handle) device data
+// ----------------------------------------------------------------------------------------
+template <typename T>
+struct DevModel {
+  int nq;
+  int axis[OS2R_MAX_DOF];
+  T rfix[OS2R_MAX_DOF][9];
+  T rpos[OS2R_MAX_DOF][3];
+  T mass[OS2R_MAX_DOF];
+  T com[OS2R_MAX_DOF][3];
+  T icom[OS2R_MAX_DOF][6];
+  T damping[OS2R_MAX_DOF];
+  T friction[OS2R_MAX_DOF];
+  T mu[OS2R_MAX_DOF];
+  int act_dof[2];
+  T max_torque[2];
+  T gravity_z;
+  int cand_begin[OS2R_MAX_DOF + 1];  // candidates of body b: [cand_begin[b], cand_begin[b+1])
+  T cand_p[OS2R_MAX_CAND][3];
+};
+
+template <typename T>
+struct DevTask {
+  int obs_dim;
+  int obs_kind[OS2R_MAX_OBS];
+  int obs_src[OS2R_MAX_OBS];
+  T obs_low[OS2R_MAX_OBS];
+  T obs_high[OS2R_MAX_OBS];
+  T done_lo[OS2R_MAX_OBS];
+  T done_hi[OS2R_MAX_OBS];
+  int reward_id, normalized;
+  int idx_pitch_pos, idx_yaw_vel, idx_hip_pos, idx_knee_pos;
+  int max_episode_steps;
+  int reset_mode, n_reset_poses;
+  int reset_pose_id[OS2R_MAX_RESET_POSES];
+  int reset_laying[OS2R_MAX_RESET_POSES];
+  double reset_pitch[OS2R_MAX_RESET_POSES];
+  double reset_hip[OS2R_MAX_RESET_POSES];
+  double reset_knee[OS2R_MAX_RESET_POSES];
+  int reset_simple;
+  double leg_def[6];
+  int dof_yaw, dof_pitch, dof_bc, dof_hip, dof_knee;
+  int randomize_params;
+  double dr_mass_lo, dr_mass_hi, dr_friction_lo, dr_friction_hi, dr_damping_lo, dr_damping_hi;
+  double dr_mu_base, dr_mu_lo, dr_mu_hi;
+  double nominal_damping[OS2R_MAX_DOF];
+};
+
+template <typename T>
+struct StepArgs {
+  const DevModel<T>* __restrict__ model;
+  const DevTask<T>* __restrict__ task;
+  long long N;
+  long long env_offset;
+  unsigned long long seed;
+  unsigned long long step_count;
+  int substeps;
+  int pgs_iters;
+  int auto_reset;
+  T dt, erp, max_erv;
+  // state, SoA
+  T* __restrict__ q;         // [nq][N]
+  T* __restrict__ qd;        // [nq][N]
+  T* __restrict__ hist;      // [2][2][N]
+  T* __restrict__ mass_scale;  // [nq][N]
+  T* __restrict__ damping;     // [nq][N]
+  T* __restrict__ friction;    // [nq][N]
+  T* __restrict__ mu;          // [nq][N]
+  T* __restrict__ gravity;     // [N]
+  int32_t* __restrict__ steps;
+  uint32_t* __restrict__ episode;
+  uint8_t* __restrict__ pose;
+  // step I/O
+  const T* __restrict__ actions;  // [N][2] or null
+  T* __restrict__ obs;            // [N][D] or null
+  T* __restrict__ reward;         // [N] or null
+  uint8_t* __restrict__ done;     // [N] or null
+  T* __restrict__ term_obs;       // [N][D] or null
+  const uint8_t* __restrict__ reset_mask;  // reset kernel only
+};
+
+// ----------------------------------------------------------------------------------------
+// counter RNG: Philox4x32-10 (Salmon et al., SC'11).  Streams and counters are part of the
+// stepper's specification (DESIGN.md "Random streams").
+// ----------------------------------------------------------------------------------------
+enum { kStreamAction = 1, kStreamReset = 2, kStreamParams = 3, kStreamGravity = 4 };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+__device__ __forceinline__ void uniform2(unsigned long long seed, uint32_t env, uint32_t stream,
+                                          uint32_t ctr, uint32_t blk, double& u0, double& u1) {
+  uint32_t o[4];
+  philox4x32_10(env, stream, ctr, blk, (uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32), o);
+  u0 = u53(o[0], o[1]);
+  u1 = u53(o[2], o[3]);
+}
+
+__device__ __forceinline__ void normal2(unsigned long long seed, uint32_t env, uint32_t stream,
+                                         uint32_t ctr, uint32_t blk, double& z0, double& z1) {
+  double u0, u1;
+  uniform2(seed, env, stream, ctr, blk, u0, u1);
+  const double r = sqrt(-2.0 * log(1.0 - u0));
+  const double th = 6.283185307179586476925286766559 * u1;
+  z0 = r * cos(th);
+  z1 = r * sin(th);
+}
+
+// ----------------------------------------------------------------------------------------
+// small vector helpers
+// ----------------------------------------------------------------------------------------
+template <typename T>
+struct V3 {
+  T x, y, z;
+};
+template <typename T> __device__ __forceinline__ V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator+(V3<T> a, V3<T> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator-(V3<T> a, V3<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename T> __device__ __forceinline__ V3<T> operator*(T s, V3<T> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> __device__ __forceinline__ V3<T> cross(V3<T> a, V3<T> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename T> __device__ __forceinline__ T comp(V3<T> a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+template <typename T> __device__ __forceinline__ void add_comp(V3<T>& a, int k, T v) {
+  if (k == 0) a.x += v; else if (k == 1) a.y += v; else a.z += v;
+}
+// R (row-major 3x3) * v   and   R^T * v
+template <typename T> __device__ __forceinline__ V3<T> rmul(const T (&R)[9], V3<T> v) {
+  return {R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z};
+}
+template <typename T> __device__ __forceinline__ V3<T> rtmul(const T (&R)[9], V3<T> v) {
+  return {R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z};
+}
+
+__device__ __forceinline__ void sincos_t(double x, double& s, double& c) { sincos(x, &s, &c); }
+__device__ __forceinline__ void sincos_t(float x, float& s, float& c) { sincosf(x, &s, &c); }
+
+// symmetric 3x3 stored as xx xy xz yy yz zz
+template <typename T> __device__ __forceinline__ V3<T> symmul(const T (&S)[6], V3<T> v) {
+  return {S[0] * v.x + S[1] * v.y + S[2] * v.z, S[1] * v.x + S[3] * v.y + S[4] * v.z, S[2] * v.x + S[4] * v.y + S[5] * v.z};
+}
+
+// Articulated inertia  [[A, H], [H^T, M]]  acting on [omega; v]:  n = A w + H v,  f = H^T w + M v
+template <typename T>
+struct ArtInertia {
+  T A[6];  // symmetric
+  T H[9];  // general, row-major
+  T M[6];  // symmetric
+};
+
+// B' = R B R^T for a general 3x3
+template <typename T> __device__ __forceinline__ void rot_general(const T (&R)[9], const T (&B)[9], T (&out)[9]) {
+  T t[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = R[3 * i] * B[j] + R[3 * i + 1] * B[3 + j] + R[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[3 * i + j] = t[3 * i] * R[3 * j] + t[3 * i + 1] * R[3 * j + 1] + t[3 * i + 2] * R[3 * j + 2];
+}
+// S' = R S R^T for a symmetric 3x3 (6 unique outputs)
+template <typename T> __device__ __forceinline__ void rot_sym(const T (&R)[9], const T (&S)[6], T (&out)[6]) {
+  const T B[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
+  T t[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = R[3 * i] * B[j] + R[3 * i + 1] * B[3 + j] + R[3 * i + 2] * B[6 + j];
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j) out[k++] = t[3 * i] * R[3 * j] + t[3 * i + 1] * R[3 * j + 1] + t[3 * i + 2] * R[3 * j + 2];
+}
+
+// ----------------------------------------------------------------------------------------
+// per-lane physical parameters: nominal (uniform, SGPR) or randomised (per lane)
+// ----------------------------------------------------------------------------------------
+template <typename T, int NQ, bool DR>
+struct Params;
+template <typename T, int NQ>
+struct Params<T, NQ, false> {
+  const DevModel<T>* m;
+  __device__ __forceinline__ T mass(int i) const { return m->mass[i]; }
+  __device__ __forceinline__ T damping(int i) const { return m->damping[i]; }
+  __device__ __forceinline__ T friction(int i) const { return m->friction[i]; }
+  __device__ __forceinline__ T mu(int i) const { return m->mu[i]; }
+  __device__ __forceinline__ T gravity() const { return m->gravity_z; }
+};
+template <typename T, int NQ>
+struct Params<T, NQ, true> {
+  const DevModel<T>* m;
+  T ms[NQ], dm[NQ], fr[NQ], mu_[NQ], g;
+  __device__ __forceinline__ T mass(int i) const { return m->mass[i] * ms[i]; }
+  __device__ __forceinline__ T damping(int i) const { return dm[i]; }
+  __device__ __forceinline__ T friction(int i) const { return fr[i]; }
+  __device__ __forceinline__ T mu(int i) const { return mu_[i]; }
+  __device__ __forceinline__ T gravity() const { return g; }
+};
+
+// ----------------------------------------------------------------------------------------
+// one physics iteration
+// ----------------------------------------------------------------------------------------
+template <typename T, int NQ, unsigned CMASK, bool DR>
+__device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, const Params<T, NQ, DR>& par,
+                                        T (&q)[NQ], T (&qd)[NQ], T tau_hip, T tau_knee, T dt, T erp,
+                                        T max_erv, int pgs_iters) {
+  // ---- 1. joint rotations R_i = Rfix_i * Rot(axis_i, q_i) (child orientation in parent) ----
+  T R[NQ][9];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    T s, c;
+    sincos_t(q[i], s, c);
+    const T* F = md->rfix[i];
+    const int ax = md->axis[i];
+    // columns a, b of F rotate into each other; column ax stays
+    const int ca = ax == 0 ? 1 : (ax == 1 ? 2 : 0);
+    const int cb = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const T fa = F[3 * r + ca], fb = F[3 * r + cb];
+      R[i][3 * r + ax] = F[3 * r + ax];
+      R[i][3 * r + ca] = c * fa + s * fb;
+      R[i][3 * r + cb] = c * fb - s * fa;
+    }
+  }
+
+  // ---- 2a. body velocities (body coordinates), outward ----
+  V3<T> w[NQ], v[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    if (i == 0) {
+      w[0] = mk<T>(0, 0, 0);
+      v[0] = mk<T>(0, 0, 0);
+    } else {
+      const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+      w[i] = rtmul(R[i], w[i - 1]);
+      v[i] = rtmul(R[i], v[i - 1] + cross(w[i - 1], r));
+    }
+    add_comp(w[i], md->axis[i], qd[i]);
+  }
+
+  // ---- 2b. articulated inertias and bias forces, inward ----
+  V3<T> Ua[NQ], Ul[NQ];  // U_i = I^A_i S_i  (angular, linear part)
+  T Dinv[NQ], u[NQ];
+  ArtInertia<T> acc;     // children's contribution, in the current body's frame
+  V3<T> pn, pf;          // children's bias force [moment; force]
+#pragma unroll
+  for (int i = NQ - 1; i >= 0; --i) {
+    const int ax = md->axis[i];
+    // rigid-body inertia of body i about its frame origin
+    const T m = par.mass(i);
+    const V3<T> cm = mk(md->com[i][0], md->com[i][1], md->com[i][2]);
+    const V3<T> h = m * cm;
+    ArtInertia<T> I;
+    I.A[0] = md->icom[i][0] + m * (cm.y * cm.y + cm.z * cm.z);
+    I.A[1] = md->icom[i][1] - m * cm.x * cm.y;
+    I.A[2] = md->icom[i][2] - m * cm.x * cm.z;
+    I.A[3] = md->icom[i][3] + m * (cm.x * cm.x + cm.z * cm.z);
+    I.A[4] = md->icom[i][4] - m * cm.y * cm.z;
+    I.A[5] = md->icom[i][5] + m * (cm.x * cm.x + cm.y * cm.y);
+    I.H[0] = 0; I.H[1] = -h.z; I.H[2] = h.y;
+    I.H[3] = h.z; I.H[4] = 0; I.H[5] = -h.x;
+    I.H[6] = -h.y; I.H[7] = h.x; I.H[8] = 0;
+    I.M[0] = m; I.M[1] = 0; I.M[2] = 0; I.M[3] = m; I.M[4] = 0; I.M[5] = m;
+    // rigid bias force v x* (I v)
+    const V3<T> nI = symmul(I.A, w[i]) + cross(h, v[i]);
+    const V3<T> fI = m * v[i] - cross(h, w[i]);
+    V3<T> pAn = cross(w[i], nI) + cross(v[i], fI);
+    V3<T> pAf = cross(w[i], fI);
+    if (i < NQ - 1) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { I.A[k] += acc.A[k]; I.M[k] += acc.M[k]; }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) I.H[k] += acc.H[k];
+      pAn = pAn + pn;
+      pAf = pAf + pf;
+    }
+    // U = I^A S : column `ax` of [[A],[H^T]]
+    const T Afull[9] = {I.A[0], I.A[1], I.A[2], I.A[1], I.A[3], I.A[4], I.A[2], I.A[4], I.A[5]};
+    Ua[i] = mk(Afull[ax], Afull[3 + ax], Afull[6 + ax]);
+    Ul[i] = mk(I.H[3 * ax], I.H[3 * ax + 1], I.H[3 * ax + 2]);
+    const T D = comp(Ua[i], ax) + dt * par.damping(i);
+    Dinv[i] = T(1) / D;
+    T tau = T(0);
+    if (i == md->act_dof[0]) tau = tau_hip;
+    if (i == md->act_dof[1]) tau = tau_knee;
+    u[i] = tau - par.damping(i) * qd[i] - comp(pAn, ax);
+    if (i > 0) {
+      // Ia = I^A - U U^T / D
+      const V3<T> ka = Dinv[i] * Ua[i], kl = Dinv[i] * Ul[i];
+      ArtInertia<T> Ia;
+      Ia.A[0] = I.A[0] - ka.x * Ua[i].x; Ia.A[1] = I.A[1] - ka.x * Ua[i].y; Ia.A[2] = I.A[2] - ka.x * Ua[i].z;
+      Ia.A[3] = I.A[3] - ka.y * Ua[i].y; Ia.A[4] = I.A[4] - ka.y * Ua[i].z; Ia.A[5] = I.A[5] - ka.z * Ua[i].z;
+      Ia.H[0] = I.H[0] - ka.x * Ul[i].x; Ia.H[1] = I.H[1] - ka.x * Ul[i].y; Ia.H[2] = I.H[2] - ka.x * Ul[i].z;
+      Ia.H[3] = I.H[3] - ka.y * Ul[i].x; Ia.H[4] = I.H[4] - ka.y * Ul[i].y; Ia.H[5] = I.H[5] - ka.y * Ul[i].z;
+      Ia.H[6] = I.H[6] - ka.z * Ul[i].x; Ia.H[7] = I.H[7] - ka.z * Ul[i].y; Ia.H[8] = I.H[8] - ka.z * Ul[i].z;
+      Ia.M[0] = I.M[0] - kl.x * Ul[i].x; Ia.M[1] = I.M[1] - kl.x * Ul[i].y; Ia.M[2] = I.M[2] - kl.x * Ul[i].z;
+      Ia.M[3] = I.M[3] - kl.y * Ul[i].y; Ia.M[4] = I.M[4] - kl.y * Ul[i].z; Ia.M[5] = I.M[5] - kl.z * Ul[i].z;
+      // velocity-product acceleration c = v x (S qd)
+      V3<T> sq = mk<T>(0, 0, 0);
+      add_comp(sq, ax, qd[i]);
+      const V3<T> ca = cross(w[i], sq), cl = cross(v[i], sq);
+      // pa = pA + Ia c + U u / D
+      const T Hfull_t0[3] = {Ia.H[0], Ia.H[3], Ia.H[6]};
+      const T Hfull_t1[3] = {Ia.H[1], Ia.H[4], Ia.H[7]};
+      const T Hfull_t2[3] = {Ia.H[2], Ia.H[5], Ia.H[8]};
+      const V3<T> Hc = mk(Ia.H[0] * cl.x + Ia.H[1] * cl.y + Ia.H[2] * cl.z, Ia.H[3] * cl.x + Ia.H[4] * cl.y + Ia.H[5] * cl.z,
+                          Ia.H[6] * cl.x + Ia.H[7] * cl.y + Ia.H[8] * cl.z);
+      const V3<T> Htc = mk(Hfull_t0[0] * ca.x + Hfull_t0[1] * ca.y + Hfull_t0[2] * ca.z,
+                           Hfull_t1[0] * ca.x + Hfull_t1[1] * ca.y + Hfull_t1[2] * ca.z,
+                           Hfull_t2[0] * ca.x + Hfull_t2[1] * ca.y + Hfull_t2[2] * ca.z);
+      const T ud = u[i] * Dinv[i];
+      const V3<T> pan = pAn + symmul(Ia.A, ca) + Hc + ud * Ua[i];
+      const V3<T> paf = pAf + Htc + symmul(Ia.M, cl) + ud * Ul[i];
+      // express in the parent frame: rotate by R_i, then shift by r_i
+      const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+      T Ar[6], Hr[9], Mr[6];
+      rot_sym(R[i], Ia.A, Ar);
+      rot_general(R[i], Ia.H, Hr);
+      rot_sym(R[i], Ia.M, Mr);
+      const T Mf[9] = {Mr[0], Mr[1], Mr[2], Mr[1], Mr[3], Mr[4], Mr[2], Mr[4], Mr[5]};
+      // H'' = Hr + r^ M  (column j: r x M[:,j])
+      T Hs[9];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const V3<T> col = cross(r, mk(Mf[j], Mf[3 + j], Mf[6 + j]));
+        Hs[j] = Hr[j] + col.x; Hs[3 + j] = Hr[3 + j] + col.y; Hs[6 + j] = Hr[6 + j] + col.z;
+      }
+      // A''[i][j] = Ar[i][j] + (r x Hr_row_j)[i] + (r x Hs_row_i)[j]
+      V3<T> x0[3], x1[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        x0[k] = cross(r, mk(Hr[3 * k], Hr[3 * k + 1], Hr[3 * k + 2]));
+        x1[k] = cross(r, mk(Hs[3 * k], Hs[3 * k + 1], Hs[3 * k + 2]));
+      }
+      acc.A[0] = Ar[0] + x0[0].x + x1[0].x;
+      acc.A[1] = Ar[1] + x0[1].x + x1[0].y;
+      acc.A[2] = Ar[2] + x0[2].x + x1[0].z;
+      acc.A[3] = Ar[3] + x0[1].y + x1[1].y;
+      acc.A[4] = Ar[4] + x0[2].y + x1[1].z;
+      acc.A[5] = Ar[5] + x0[2].z + x1[2].z;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc.H[k] = Hs[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc.M[k] = Mr[k];
+      pf = rmul(R[i], paf);
+      pn = rmul(R[i], pan) + cross(r, pf);
+    }
+  }
+
+  // ---- 2c. accelerations, outward; the base accelerates by -g (gravity as a fictitious force) ----
+  T vs[NQ];  // predicted velocity v* = qd + dt*qdd
+  {
+    V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, -par.gravity());
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int ax = md->axis[i];
+      const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+      V3<T> sq = mk<T>(0, 0, 0);
+      add_comp(sq, ax, qd[i]);
+      const V3<T> pa_ = rtmul(R[i], aa);
+      const V3<T> pl_ = rtmul(R[i], al + cross(aa, r));
+      aa = pa_ + cross(w[i], sq);
+      al = pl_ + cross(v[i], sq);
+      const T qdd = (u[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
+      add_comp(aa, ax, qdd);
+      vs[i] = qd[i] + dt * qdd;
+    }
+  }
+
+  // ---- 3. inverse of (M + dt*diag(d)): unit-torque sweeps, upper triangle ----
+  T Mi[NQ][NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    T uk[NQ];
+    uk[k] = T(1);
+    V3<T> pn_ = Dinv[k] * Ua[k], pf_ = Dinv[k] * Ul[k];
+#pragma unroll
+    for (int i = k - 1; i >= 0; --i) {
+      // bias force of body i+1 expressed in body i
+      const V3<T> r = mk(md->rpos[i + 1][0], md->rpos[i + 1][1], md->rpos[i + 1][2]);
+      const V3<T> f = rmul(R[i + 1], pf_);
+      const V3<T> n = rmul(R[i + 1], pn_) + cross(r, f);
+      uk[i] = -comp(n, md->axis[i]);
+      const T s = uk[i] * Dinv[i];
+      pn_ = n + s * Ua[i];
+      pf_ = f + s * Ul[i];
+    }
+    V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      if (i > 0) {
+        const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+        const V3<T> na = rtmul(R[i], aa);
+        al = rtmul(R[i], al + cross(aa, r));
+        aa = na;
+      }
+      const T x = (uk[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
+      Mi[i][k] = x;
+      Mi[k][i] = x;
+      add_comp(aa, md->axis[i], x);
+    }
+  }
+
+  // ---- 5. ground contact candidates -> one point contact per body ----
+  // rows live in registers with static indexing; bodies without candidates compile out (CMASK)
+  constexpr int NB = NQ;
+  T Jn[NB][NQ], Jx[NB][NQ], Jy[NB][NQ];  // Jacobian rows: normal z, tangents x, y
+  T Tn[NB][NQ], Tx[NB][NQ], Ty[NB][NQ];  // Minv * J^T
+  T dn[NB], dx[NB], dy[NB], erv[NB];
+  bool act[NB];
+  bool wave_act[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { act[b] = false; wave_act[b] = false; }
+  if (CMASK != 0u) {
+    T Rw[9], ow[3];
+    V3<T> aw[NQ], jo[NQ];  // world joint axes and joint origins
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const V3<T> r = mk(md->rpos[b][0], md->rpos[b][1], md->rpos[b][2]);
+      if (b == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rw[k] = R[0][k];
+        ow[0] = r.x; ow[1] = r.y; ow[2] = r.z;
+      } else {
+        const V3<T> t = rmul(Rw, r);
+        ow[0] += t.x; ow[1] += t.y; ow[2] += t.z;
+        T n[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) n[3 * i + j] = Rw[3 * i] * R[b][j] + Rw[3 * i + 1] * R[b][3 + j] + Rw[3 * i + 2] * R[b][6 + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rw[k] = n[k];
+      }
+      const int ax = md->axis[b];
+      aw[b] = mk(Rw[ax], Rw[3 + ax], Rw[6 + ax]);
+      jo[b] = mk(ow[0], ow[1], ow[2]);
+      if (!((CMASK >> b) & 1u)) continue;
+      const int k0 = md->cand_begin[b], k1 = md->cand_begin[b + 1];
+      T W = 0, sx = 0, sy = 0, sz = 0;
+      for (int k = k0; k < k1; ++k) {
+        const T px = md->cand_p[k][0], py = md->cand_p[k][1], pz = md->cand_p[k][2];
+        const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
+        const T wgt = z < T(0) ? -z : T(0);
+        W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+      }
+      act[b] = W > T(0);
+      wave_act[b] = __ballot(act[b]) != 0ull;
+      if (wave_act[b]) {
+        const T iw = act[b] ? T(1) / W : T(0);
+        const V3<T> pc = mk(sx * iw, sy * iw, sz * iw);
+        const V3<T> pw = rmul(Rw, pc) + jo[b];
+        const T depth = -pw.z;
+        const T e = erp * depth / dt;
+        erv[b] = e > max_erv ? max_erv : e;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+          if (j <= b) {
+            const V3<T> c = cross(aw[j], pw - jo[j]);
+            Jx[b][j] = c.x; Jy[b][j] = c.y; Jn[b][j] = c.z;
+          } else {
+            Jx[b][j] = 0; Jy[b][j] = 0; Jn[b][j] = 0;
+          }
+        }
+        T sdn = 0, sdx = 0, sdy = 0;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+          T tn = 0, tx = 0, ty = 0;
+#pragma unroll
+          for (int j = 0; j <= b; ++j) { tn += Mi[i][j] * Jn[b][j]; tx += Mi[i][j] * Jx[b][j]; ty += Mi[i][j] * Jy[b][j]; }
+          Tn[b][i] = tn; Tx[b][i] = tx; Ty[b][i] = ty;
+        }
+#pragma unroll
+        for (int j = 0; j <= b; ++j) { sdn += Jn[b][j] * Tn[b][j]; sdx += Jx[b][j] * Tx[b][j]; sdy += Jy[b][j] * Ty[b][j]; }
+        dn[b] = sdn; dx[b] = sdx; dy[b] = sdy;
+      }
+    }
+  }
+
+  // ---- 6. projected Gauss-Seidel on the velocities ----
+  T ln[NB], lx[NB], ly[NB], lf[NQ];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { ln[b] = 0; lx[b] = 0; ly[b] = 0; }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) lf[j] = 0;
+  T fb[NQ];  // joint friction impulse bound
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) fb[j] = par.friction(j) * dt;
+
+  for (int it = 0; it < pgs_iters; ++it) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (!wave_act[b]) continue;
+      const bool on = act[b];
+      // normal row: lambda >= 0, target velocity erv
+      {
+        T res = -erv[b];
+#pragma unroll
+        for (int j = 0; j <= b; ++j) res += Jn[b][j] * vs[j];
+        T lam = ln[b] - res / dn[b];
+        lam = lam < T(0) ? T(0) : lam;
+        lam = (on && dn[b] > T(0)) ? lam : ln[b];
+        const T dl = lam - ln[b];
+        ln[b] = lam;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) vs[j] += Tn[b][j] * dl;
+      }
+      const T lim = par.mu(b) * ln[b];
+      {
+        T res = 0;
+#pragma unroll
+        for (int j = 0; j <= b; ++j) res += Jx[b][j] * vs[j];
+        T lam = lx[b] - res / dx[b];
+        lam = lam < -lim ? -lim : lam;
+        lam = lam > lim ? lim : lam;
+        lam = (on && dx[b] > T(0)) ? lam : lx[b];
+        const T dl = lam - lx[b];
+        lx[b] = lam;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) vs[j] += Tx[b][j] * dl;
+      }
+      {
+        T res = 0;
+#pragma unroll
+        for (int j = 0; j <= b; ++j) res += Jy[b][j] * vs[j];
+        T lam = ly[b] - res / dy[b];
+        lam = lam < -lim ? -lim : lam;
+        lam = lam > lim ? lim : lam;
+        lam = (on && dy[b] > T(0)) ? lam : ly[b];
+        const T dl = lam - ly[b];
+        ly[b] = lam;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) vs[j] += Ty[b][j] * dl;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      // joint Coulomb friction row: J = e_j, T = Minv[:, j], d = Minv[j][j]
+      T lam = lf[j] - vs[j] / Mi[j][j];
+      lam = lam < -fb[j] ? -fb[j] : lam;
+      lam = lam > fb[j] ? fb[j] : lam;
+      lam = (fb[j] > T(0) && Mi[j][j] > T(0)) ? lam : lf[j];
+      const T dl = lam - lf[j];
+      lf[j] = lam;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) vs[i] += Mi[i][j] * dl;
+    }
+  }
+
+  // ---- 7. semi-implicit Euler ----
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    qd[i] = vs[i];
+    q[i] += dt * vs[i];
+  }
+}
+
+}  // namespace os2r

@@ -1,0 +1,448 @@
+// os2r_kernels.hpp — step / reset kernels: substeps + fused epilogue (observation, reward, done,
+// auto-reset) in one launch.  Included by the per-dtype instantiation units.
+#pragma once
+#include "os2r_device.hpp"
+
+namespace os2r {
+
+// ----------------------------------------------------------------------------------------
+// epilogue pieces.  Contraction is switched off so that the f64 path performs exactly the
+// operations numpy performs in the reference (tasks/monopod.py:257-272, rewards/*.py): the
+// affine maps, the periodic wrap and the polynomial sigmoids are then bit-identical.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
+__device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
+__device__ __forceinline__ double fmod_t(double a, double b) { return fmod(a, b); }
+__device__ __forceinline__ float fmod_t(float a, float b) { return fmodf(a, b); }
+__device__ __forceinline__ double sqrt_t(double x) { return sqrt(x); }
+__device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
+__device__ __forceinline__ double fabs_t(double x) { return fabs(x); }
+__device__ __forceinline__ float fabs_t(float x) { return fabsf(x); }
+__device__ __forceinline__ double atanh_t(double x) { return atanh(x); }
+__device__ __forceinline__ float atanh_t(float x) { return atanhf(x); }
+
+// numpy.mod(x + pi, 2*pi) - pi
+template <typename T>
+__device__ __forceinline__ T wrap_pi(T x) {
+#pragma clang fp contract(off)
+  const T pi = T(3.141592653589793238462643383279502884);
+  const T two_pi = T(2) * pi;
+  T m = fmod_t(x + pi, two_pi);
+  if (m != T(0)) {
+    if (m < T(0)) m += two_pi;
+  } else {
+    m = T(0);
+  }
+  return m - pi;
+}
+
+// value before the affine / tanh map, and the observation itself (tasks/monopod.py:238-272)
+template <typename T, int NQ>
+__device__ __forceinline__ void observe(const DevTask<T>* __restrict__ ts, const T (&q)[NQ], const T (&qd)[NQ],
+                                        T h1a, T h1b, T (&obs)[OS2R_MAX_OBS], bool& done) {
+#pragma clang fp contract(off)
+  done = false;
+  const int D = ts->obs_dim;
+#pragma unroll
+  for (int d = 0; d < OS2R_MAX_OBS; ++d) {
+    if (d >= D) { obs[d] = T(0); continue; }
+    const int kind = ts->obs_kind[d], s = ts->obs_src[d];
+    T x = T(0);
+    if (kind == OS2R_OBS_TORQUE_NORM || kind == OS2R_OBS_TORQUE_RAW) {
+      x = s == 0 ? h1a : h1b;
+    } else if (kind == OS2R_OBS_VEL_TANH || kind == OS2R_OBS_VEL_RAW) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) x = (s == i) ? qd[i] : x;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) x = (s == i) ? q[i] : x;
+    }
+    if (kind == OS2R_OBS_POS_PERIODIC_NORM || kind == OS2R_OBS_POS_PERIODIC_RAW) x = wrap_pi(x);
+    // done: the reference tests the observation against reset_space; done_lo/done_hi are the
+    // exact pre-images of that test on x (host-side bisection), NaN counts as done
+    if (!(x >= ts->done_lo[d] && x <= ts->done_hi[d])) done = true;
+    T o = x;
+    if (kind == OS2R_OBS_POS_NORM || kind == OS2R_OBS_POS_PERIODIC_NORM || kind == OS2R_OBS_TORQUE_NORM) {
+      const T lo = ts->obs_low[d], hi = ts->obs_high[d];
+      o = T(2) * (x - lo) / (hi - lo) - T(1);
+    } else if (kind == OS2R_OBS_VEL_TANH) {
+      o = tanh_t(T(0.05) * x);
+    }
+    obs[d] = o;
+  }
+}
+
+// rewards_utils.py:76-122 restricted to the sigmoids the reward classes use
+template <typename T>
+__device__ __forceinline__ T tol_quadratic(T x, T margin, T value_at_margin) {  // bounds (0,0)
+#pragma clang fp contract(off)
+  if (x == T(0)) return T(1);
+  const T d = (x < T(0) ? T(0) - x : x - T(0)) / margin;
+  const T sx = d * sqrt_t(T(1) - value_at_margin);
+  return fabs_t(sx) < T(1) ? T(1) - sx * sx : T(0);
+}
+template <typename T>
+__device__ __forceinline__ T tol_linear(T x, T margin, T value_at_margin) {  // bounds (0,0)
+#pragma clang fp contract(off)
+  if (x == T(0)) return T(1);
+  const T d = (x < T(0) ? T(0) - x : x - T(0)) / margin;
+  const T sx = d * (T(1) - value_at_margin);
+  return fabs_t(sx) < T(1) ? T(1) - sx : T(0);
+}
+
+template <typename T>
+__device__ __forceinline__ T pick_obs(const T (&obs)[OS2R_MAX_OBS], int idx) {
+  T x = T(0);
+#pragma unroll
+  for (int d = 0; d < OS2R_MAX_OBS; ++d) x = (d == idx) ? obs[d] : x;
+  return x;
+}
+
+// rewards/__init__.py:66-207.  a0 = actions[0] (just applied), a1 = actions[1] (previous)
+template <typename T>
+__device__ __forceinline__ T reward_of(const DevTask<T>* __restrict__ ts, const T (&obs)[OS2R_MAX_OBS], T a0x, T a0y,
+                                       T a1x, T a1y) {
+#pragma clang fp contract(off)
+  const T nrm = ts->normalized ? T(1) : T(0);
+  const T H = T(0.11) / T(1.57) * nrm + T(0.11) * (T(1) - nrm);
+  const T bp = pick_obs(obs, ts->idx_pitch_pos);
+  const T lo = H, hi = T(4) * H;
+  const bool inb = (lo <= bp) && (bp <= hi);
+  const T window = inb ? T(1) : T(0);
+  switch (ts->reward_id) {
+    case OS2R_REWARD_BALANCING_V1:
+    case OS2R_REWARD_STANDING_V1:
+      return window;
+    case OS2R_REWARD_BALANCING_V2:
+      return window * (tol_quadratic(a0x, T(1), T(0.4)) * tol_quadratic(a0y, T(1), T(0.4)));
+    case OS2R_REWARD_BALANCING_V3: {
+      T bal = T(1);
+      if (!inb) {  // long_tail, margin 0.01, value_at_margin 0.1
+        const T d = (bp < lo ? lo - bp : bp - hi) / T(0.01);
+        const T t = d * sqrt_t(T(1) / T(0.1) - T(1));
+        bal = T(1) / (t * t + T(1));
+      }
+      return bal * (tol_quadratic(a0x - a1x, T(1), T(0.1)) * tol_quadratic(a0y - a1y, T(1), T(0.1)));
+    }
+    case OS2R_REWARD_HOPPING_V1: {
+      const T sd = tol_quadratic(a0x - a1x, T(0.1), T(0)) * tol_quadratic(a0y - a1y, T(0.1), T(0));
+      const T hv = pick_obs(obs, ts->idx_yaw_vel);
+      T move = T(1);
+      if (!((T(0.25) <= hv) && (hv <= T(0.3)))) {  // tanh_squared, margin 0.15, value_at_margin 0.1
+        const T d = (hv < T(0.25) ? T(0.25) - hv : hv - T(0.3)) / T(0.15);
+        const T th = tanh_t(d * atanh_t(sqrt_t(T(1) - T(0.1))));
+        move = T(1) - th * th;
+      }
+      return window * sd * move;
+    }
+    case OS2R_REWARD_STRAIGHT_V1: {
+      T sc = (tol_quadratic(a0x / T(20), T(1), T(0)) + tol_quadratic(a0y / T(20), T(1), T(0))) / T(2);
+      sc = (T(4) + sc) / T(5);
+      const T hr = tol_linear(pick_obs(obs, ts->idx_hip_pos), T(1), T(0.1));
+      const T kr = tol_linear(pick_obs(obs, ts->idx_knee_pos), T(1), T(0.1));
+      return hr * kr * sc;
+    }
+    default:
+      return T(0);
+  }
+}
+
+// utils/reset.py:4-40
+__device__ __forceinline__ void leg_joint_angles(const double (&def6)[6], double pitch, double& hip, double& knee) {
+#pragma clang fp contract(off)
+  const double ul = def6[0], ll = def6[1], cph = def6[2], lb = def6[3];
+  const double lh = (lb * sin(pitch) + cph) / cos(pitch);
+  const double lleg = lh - def6[4] - def6[5];
+  if (lleg > ul + ll) { hip = 0.0; knee = 0.0; return; }
+  const double ua = acos((ul * ul + lleg * lleg - ll * ll) / (2.0 * ul * lleg));
+  const double la = asin(ul * sin(ua) / ll) + ua;
+  hip = ua;
+  knee = -la;
+}
+
+// Reset of one environment: randomizers/monopod_no_rand.py:59-98 (fixed) and
+// randomizers/monopod.py:89-128,182-215 (randomised pose + parameter resampling).
+template <typename T, int NQ, bool DR>
+__device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uint32_t epi, T (&q)[NQ], T (&qd)[NQ],
+                                          Params<T, NQ, DR>& par, uint8_t& pose) {
+#pragma clang fp contract(off)
+  const DevTask<T>* __restrict__ ts = A.task;
+  const uint32_t genv = (uint32_t)(A.env_offset + e);
+  double u0, u1;
+  uniform2(A.seed, genv, kStreamReset, epi, 0, u0, u1);
+  int pi = (int)(u0 * ts->n_reset_poses);
+  if (pi >= ts->n_reset_poses) pi = ts->n_reset_poses - 1;
+  double pitch = 0, hip = 0, knee = 0, yaw = 0;
+  int laying = 0, pid = 0;
+  for (int k = 0; k < OS2R_MAX_RESET_POSES; ++k) {
+    if (k == pi) { pitch = ts->reset_pitch[k]; hip = ts->reset_hip[k]; knee = ts->reset_knee[k]; laying = ts->reset_laying[k]; pid = ts->reset_pose_id[k]; }
+  }
+  if (ts->reset_mode == OS2R_RESET_FIXED) {
+    if (ts->reset_simple) {
+      double w0, w1;
+      uniform2(A.seed, genv, kStreamReset, epi, 1, w0, w1);
+      hip = 2.0 * w0 - 1.0;
+      knee = 2.0 * w1 - 1.0;
+    }
+  } else {
+    pitch *= 0.8 + 0.4 * u1;
+    double z0, z1, w0, w1, x0, x1;
+    normal2(A.seed, genv, kStreamReset, epi, 1, z0, z1);
+    uniform2(A.seed, genv, kStreamReset, epi, 2, w0, w1);
+    uniform2(A.seed, genv, kStreamReset, epi, 3, x0, x1);
+    const double r0 = fabs(0.2 * z0), r1 = fabs(0.2 * z1);
+    const double rmax = r0 > r1 ? r0 : r1, rmin = r0 > r1 ? r1 : r0;
+    if (!laying) {
+      double def6[6];
+      for (int k = 0; k < 6; ++k) def6[k] = ts->leg_def[k];
+      leg_joint_angles(def6, pitch, hip, knee);
+    } else {
+      hip = 1.57 - (w0 < 0.5 ? 3.14 : 0.0);
+      knee = 0.0;
+    }
+    hip = hip + (hip > 0.0 ? 1.0 : 0.0) * rmax;
+    knee = knee - (knee > 0.0 ? 1.0 : 0.0) * rmin;
+    const double dir = 1.0 - (w1 < 0.5 ? 2.0 : 0.0);
+    hip *= dir;
+    knee *= dir;
+    yaw = -0.2 + 0.4 * x0;
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    double v = 0.0;
+    if (i == ts->dof_pitch) v = pitch;
+    if (i == ts->dof_yaw) v = yaw;
+    if (i == ts->dof_hip) v = hip;
+    if (i == ts->dof_knee) v = knee;
+    q[i] = (T)v;
+    qd[i] = T(0);
+  }
+  pose = (uint8_t)pid;
+  if constexpr (DR) {
+    if (ts->reset_mode == OS2R_RESET_RANDOM && ts->randomize_params) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        double a0, a1, b0, b1;
+        uniform2(A.seed, genv, kStreamParams, epi, 2 * i, a0, a1);
+        uniform2(A.seed, genv, kStreamParams, epi, 2 * i + 1, b0, b1);
+        par.ms[i] = (T)(ts->dr_mass_lo + (ts->dr_mass_hi - ts->dr_mass_lo) * a0);
+        par.fr[i] = (T)(ts->dr_friction_lo + (ts->dr_friction_hi - ts->dr_friction_lo) * a1);
+        par.dm[i] = (T)(ts->nominal_damping[i] * (ts->dr_damping_lo + (ts->dr_damping_hi - ts->dr_damping_lo) * b0));
+        par.mu_[i] = (T)(ts->dr_mu_base * (ts->dr_mu_lo + (ts->dr_mu_hi - ts->dr_mu_lo) * b1));
+      }
+    }
+  }
+}
+
+template <typename T, int NQ, bool DR>
+__device__ __forceinline__ void load_params(const StepArgs<T>& A, long long e, Params<T, NQ, DR>& par) {
+  par.m = A.model;
+  if constexpr (DR) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      par.ms[i] = A.mass_scale[i * A.N + e];
+      par.dm[i] = A.damping[i * A.N + e];
+      par.fr[i] = A.friction[i * A.N + e];
+      par.mu_[i] = A.mu[i * A.N + e];
+    }
+    par.g = A.gravity[e];
+  }
+}
+template <typename T, int NQ, bool DR>
+__device__ __forceinline__ void store_params(const StepArgs<T>& A, long long e, const Params<T, NQ, DR>& par) {
+  if constexpr (DR) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      A.mass_scale[i * A.N + e] = par.ms[i];
+      A.damping[i * A.N + e] = par.dm[i];
+      A.friction[i * A.N + e] = par.fr[i];
+      A.mu[i * A.N + e] = par.mu_[i];
+    }
+  }
+}
+
+// Coalesced [N][D] row-major store of one wave's observation tile: the 64 rows of a wave are
+// one contiguous block of 64*D values, so the tile goes through LDS and is written in lane order.
+template <typename T>
+__device__ __forceinline__ void store_obs_tile(T* __restrict__ dst, const T (&obs)[OS2R_MAX_OBS], int D, long long e0,
+                                               long long N, int lane, T* tile) {
+#pragma unroll
+  for (int d = 0; d < OS2R_MAX_OBS; ++d)
+    if (d < D) tile[lane * D + d] = obs[d];
+  __syncthreads();
+  const long long rows = (N - e0) < (long long)kWave ? (N - e0) : (long long)kWave;
+  const int total = (int)rows * D;
+  for (int k = lane; k < total; k += kWave) dst[e0 * D + k] = tile[k];
+  __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------
+// env-step kernel: GazeboRuntime.step (runtimes/gazebo_runtime.py:65-97) for every env
+// ----------------------------------------------------------------------------------------
+template <typename T, int NQ, unsigned CMASK, bool DR>
+__global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
+  __shared__ T tile[kWave * OS2R_MAX_OBS];
+  const int lane = threadIdx.x;
+  const long long e0 = (long long)blockIdx.x * kWave;
+  const bool valid = e0 + lane < A.N;
+  const long long e = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
+  const DevModel<T>* __restrict__ md = A.model;
+  const DevTask<T>* __restrict__ ts = A.task;
+
+  T q[NQ], qd[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    q[i] = A.q[i * A.N + e];
+    qd[i] = A.qd[i * A.N + e];
+  }
+  Params<T, NQ, DR> par;
+  load_params<T, NQ, DR>(A, e, par);
+
+  // action: caller-provided or drawn from the counter RNG (stream 1, counter = step count)
+  T ax, ay;
+  if (A.actions) {
+    ax = A.actions[2 * e];
+    ay = A.actions[2 * e + 1];
+  } else {
+    double u0, u1;
+    uniform2(A.seed, (uint32_t)(A.env_offset + e), kStreamAction, (uint32_t)A.step_count,
+             (uint32_t)(A.step_count >> 32), u0, u1);
+    ax = (T)(2.0 * u0 - 1.0);
+    ay = (T)(2.0 * u1 - 1.0);
+  }
+  ax = ax < T(-1) ? T(-1) : (ax > T(1) ? T(1) : ax);
+  ay = ay < T(-1) ? T(-1) : (ay > T(1) ? T(1) : ay);
+  T tau_hip, tau_knee, asx, asy;
+  {
+#pragma clang fp contract(off)
+    tau_hip = md->max_torque[0] * ax;    // tasks/monopod.py:223
+    tau_knee = md->max_torque[1] * ay;
+    asx = tau_hip / md->max_torque[0];   // what action_history stores (:233-235)
+    asy = tau_knee / md->max_torque[1];
+  }
+
+  for (int s = 0; s < A.substeps; ++s)  // runtimes/gazebo_runtime.py:70-77
+    substep<T, NQ, CMASK, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.pgs_iters);
+
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) bad = bad || !(fabs_t(q[i]) < T(1e30)) || !(fabs_t(qd[i]) < T(1e30));
+
+  const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
+  T obs[OS2R_MAX_OBS];
+  bool dn;
+  observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn);
+  const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
+  int steps = A.steps[e] + 1;
+  const bool trunc = ts->max_episode_steps > 0 && steps >= ts->max_episode_steps;
+  const uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
+  const int D = ts->obs_dim;
+
+  if (A.term_obs) store_obs_tile<T>(A.term_obs, obs, D, e0, A.N, lane, tile);
+
+  uint32_t epi = A.episode[e];
+  uint8_t pose = A.pose[e];
+  const bool do_reset = flag != 0 && A.auto_reset != 0;
+  if (__ballot(do_reset) != 0ull) {
+    if (do_reset) {
+      reset_env<T, NQ, DR>(A, e, epi, q, qd, par, pose);
+      epi += 1;
+      steps = 0;
+      bool dn2;
+      observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn2);
+    }
+  }
+  if (A.obs) store_obs_tile<T>(A.obs, obs, D, e0, A.N, lane, tile);
+
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      A.q[i * A.N + e] = q[i];
+      A.qd[i * A.N + e] = qd[i];
+    }
+    A.hist[2 * A.N + e] = h1x;
+    A.hist[3 * A.N + e] = h1y;
+    A.hist[0 * A.N + e] = asx;
+    A.hist[1 * A.N + e] = asy;
+    A.steps[e] = steps;
+    if (do_reset) {
+      A.episode[e] = epi;
+      A.pose[e] = pose;
+      store_params<T, NQ, DR>(A, e, par);
+    }
+    if (A.reward) A.reward[e] = rew;
+    if (A.done) A.done[e] = flag;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// masked reset kernel: GazeboEnvRandomizer.reset -> randomize_task -> get_observation
+// ----------------------------------------------------------------------------------------
+template <typename T, int NQ, bool DR>
+__global__ __launch_bounds__(kWave) void reset_kernel(const StepArgs<T> A) {
+  __shared__ T tile[kWave * OS2R_MAX_OBS];
+  const int lane = threadIdx.x;
+  const long long e0 = (long long)blockIdx.x * kWave;
+  const bool valid = e0 + lane < A.N;
+  const long long e = valid ? e0 + lane : A.N - 1;
+  const DevTask<T>* __restrict__ ts = A.task;
+  T q[NQ], qd[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    q[i] = A.q[i * A.N + e];
+    qd[i] = A.qd[i * A.N + e];
+  }
+  Params<T, NQ, DR> par;
+  load_params<T, NQ, DR>(A, e, par);
+  const bool doit = A.reset_mask ? A.reset_mask[e] != 0 : true;
+  uint32_t epi = A.episode[e];
+  uint8_t pose = A.pose[e];
+  if (doit) {
+    reset_env<T, NQ, DR>(A, e, epi, q, qd, par, pose);
+    epi += 1;
+  }
+  const T h1x = A.hist[2 * A.N + e], h1y = A.hist[3 * A.N + e];
+  T obs[OS2R_MAX_OBS];
+  bool dn;
+  observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn);
+  if (A.obs) store_obs_tile<T>(A.obs, obs, ts->obs_dim, e0, A.N, lane, tile);
+  if (valid && doit) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      A.q[i * A.N + e] = q[i];
+      A.qd[i * A.N + e] = qd[i];
+    }
+    A.episode[e] = epi;
+    A.pose[e] = pose;
+    A.steps[e] = 0;
+    store_params<T, NQ, DR>(A, e, par);
+  }
+}
+
+// per-env gravity drawn once at create (randomizers/monopod.py:56-61)
+template <typename T>
+__global__ void gravity_kernel(T* __restrict__ gravity, long long N, long long env_offset, unsigned long long seed,
+                               double mean, double std_) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  double z0, z1;
+  normal2(seed, (uint32_t)(env_offset + e), kStreamGravity, 0, 0, z0, z1);
+  gravity[e] = (T)(mean + std_ * z0);
+}
+
+template <typename T>
+__global__ void fill_kernel(T* __restrict__ dst, long long n, T value) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = value;
+}
+
+// launch tables (defined in the per-dtype instantiation units)
+template <typename T>
+struct Launcher {
+  static int step(int nq, unsigned cmask, bool dr, const StepArgs<T>& args, hipStream_t stream);
+  static int reset(int nq, bool dr, const StepArgs<T>& args, hipStream_t stream);
+  static void gravity(T* g, long long N, long long off, unsigned long long seed, double mean, double std_, hipStream_t s);
+  static void fill(T* dst, long long n, T value, hipStream_t s);
+};
+
+}  // namespace os2r

@@ -1,0 +1,148 @@
+"""Thin Python handle over one ``Os2rSim`` of the C-ABI: torch tensors in, torch tensors out.
+
+torch is used only for device memory and the current HIP stream; every call goes straight
+to ``libos2r.so``.  All tensors stay on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib, abi
+
+
+class Os2rError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipSim:
+    """N environments resident on one GPU."""
+
+    def __init__(self, cfg: abi.Os2rConfig, device: Optional[torch.device] = None):
+        self._lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise Os2rError("no GPU visible: the stepper runs on MI355X only (no CPU fallback)")
+        self.device = torch.device(device if device is not None else f"cuda:{cfg.device}")
+        if self.device.index is not None:
+            cfg.device = self.device.index
+        self.cfg = cfg
+        self.N, self.nq, self.D = int(cfg.num_envs), int(cfg.model.nq), int(cfg.task.obs_dim)
+        self.dtype = torch.float64 if cfg.dtype == abi.F64 else torch.float32
+        self._h = C.c_void_p()
+        rc = self._lib.os2r_create(C.byref(cfg), C.byref(self._h))
+        if rc != abi.OK:
+            raise Os2rError(f"os2r_create failed ({rc}): {self._lib.os2r_last_error(None).decode()}")
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != abi.OK:
+            raise Os2rError(f"{what} failed ({rc}): {self._lib.os2r_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _new(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    def _in(self, t, shape, dtype=None):
+        t = torch.as_tensor(t, device=self.device).to(dtype or self.dtype).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.os2r_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- hot path ---------------------------------------------------------------------------
+    def step(self, actions: Optional[torch.Tensor] = None, want_terminal: bool = True):
+        """-> obs [N,D], reward [N], done [N] uint8 flags, terminal_obs [N,D] or None."""
+        a = None if actions is None else self._in(actions, (self.N, 2))
+        obs, rew = self._new(self.N, self.D), self._new(self.N)
+        done = self._new(self.N, dtype=torch.uint8)
+        term = self._new(self.N, self.D) if want_terminal else None
+        self._check(self._lib.os2r_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term),
+                                        self._stream()), "os2r_step")
+        return obs, rew, done, term
+
+    def step_into(self, actions, obs, rew, done, term=None):
+        """Allocation-free variant writing into caller tensors."""
+        self._check(self._lib.os2r_step(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term),
+                                        self._stream()), "os2r_step")
+
+    def reset(self, mask: Optional[torch.Tensor] = None):
+        m = None if mask is None else self._in(mask, (self.N,), torch.uint8)
+        obs = self._new(self.N, self.D)
+        self._check(self._lib.os2r_reset(self._h, _ptr(m), _ptr(obs), self._stream()), "os2r_reset")
+        return obs
+
+    def bench_steps(self, nsteps: int) -> float:
+        """GPU milliseconds (HIP events on the current stream) for nsteps random-action steps."""
+        ms = C.c_float()
+        self._check(self._lib.os2r_bench_steps(self._h, int(nsteps), self._stream(), C.byref(ms)), "os2r_bench_steps")
+        return float(ms.value)
+
+    # -- state ------------------------------------------------------------------------------
+    def get_state(self):
+        q, qd = self._new(self.nq, self.N), self._new(self.nq, self.N)
+        self._check(self._lib.os2r_get_state(self._h, _ptr(q), _ptr(qd), self._stream()), "os2r_get_state")
+        return q, qd
+
+    def set_state(self, q=None, qd=None):
+        q = None if q is None else self._in(q, (self.nq, self.N))
+        qd = None if qd is None else self._in(qd, (self.nq, self.N))
+        self._check(self._lib.os2r_set_state(self._h, _ptr(q), _ptr(qd), self._stream()), "os2r_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+
+    def get_action_history(self, which: int):
+        out = self._new(2, self.N)
+        self._check(self._lib.os2r_get_action_history(self._h, int(which), _ptr(out), self._stream()),
+                    "os2r_get_action_history")
+        return out
+
+    def set_action_history(self, which: int, value):
+        v = self._in(value, (2, self.N))
+        self._check(self._lib.os2r_set_action_history(self._h, int(which), _ptr(v), self._stream()),
+                    "os2r_set_action_history")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def get_params(self, field: int):
+        out = self._new(1 if field == abi.PARAM_GRAVITY else self.nq, self.N)
+        self._check(self._lib.os2r_get_params(self._h, int(field), _ptr(out), self._stream()), "os2r_get_params")
+        return out
+
+    def set_params(self, field: int, value):
+        v = self._in(value, (1 if field == abi.PARAM_GRAVITY else self.nq, self.N))
+        self._check(self._lib.os2r_set_params(self._h, int(field), _ptr(v), self._stream()), "os2r_set_params")
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def episode_info(self):
+        steps = self._new(self.N, dtype=torch.int32)
+        epi = self._new(self.N, dtype=torch.int32)   # uint32 payload
+        pose = self._new(self.N, dtype=torch.uint8)
+        self._check(self._lib.os2r_get_episode_info(self._h, _ptr(steps), _ptr(epi), _ptr(pose), self._stream()),
+                    "os2r_get_episode_info")
+        return steps, epi, pose
+
+    @property
+    def step_count(self) -> int:
+        v = C.c_uint64()
+        self._check(self._lib.os2r_get_step_count(self._h, C.byref(v)), "os2r_get_step_count")
+        return int(v.value)
+
+    @step_count.setter
+    def step_count(self, value: int):
+        self._check(self._lib.os2r_set_step_count(self._h, C.c_uint64(int(value))), "os2r_set_step_count")
