@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Env-step throughput of the HIP monopod stepper (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one env-step launch over this rank's batch: 10 physics iterations with the action
+held + observation/reward/done + auto-reset, random actions drawn on device (no H2D on the timed
+path).  Default workload = BASELINE configuration C4 (the per-GPU share of C5): 65 536 envs of the
+free-boom balancing task (task_mode 'free_hip', BalancingV1) with ground contact and per-env domain
+randomisation (link mass, joint damping/friction, ground friction, gravity), randomised resets.
+Envs shard embarrassingly over ranks (contiguous ranges, no data-path collective): weak scaling.
+
+Rank 0 prints ONE JSON line: the contract keys plus
+  roofline      HBM view of the step kernel (algorithmic bytes / HIP-event kernel time)
+  roofline_valu fp64 vector-ALU view of the same kernel (the resource that actually binds)
+  cpu_baseline  the CPU oracle (scalar fp64 port) timed on this box's host cores, N=1 only
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6     # MI355X fp64 vector peak (half the 157.3 TF fp32 vector rate)
+FP32_VECTOR_PEAK_TF = 157.3
+
+WORKLOADS = {
+    # name: (task_mode, reward, contact, domain randomisation, description)
+    "C2": ("fixed_hip", "BalancingV1", False, False, "4096 envs fixed_hip, ground contact off, random actions"),
+    "C3": ("free_hip", "BalancingV1", True, False, "65536 envs free_hip balancing with ground contact"),
+    "C4": ("free_hip", "BalancingV1", True, True,
+           "65536 envs/GPU free_hip balancing, ground contact, per-env domain randomisation (C5 = 8 x C4)"),
+}
+
+
+def build_config(args, rank, world):
+    import gym_os2r_amd as g
+    from gym_os2r_amd import abi, rewards
+    from gym_os2r_amd.tasks.monopod import MonopodTask
+    mode, reward, contact, dr, _ = WORKLOADS[args.workload]
+    task = MonopodTask(1000, task_mode=mode, reward_class=getattr(rewards, reward), reset_positions=["stand"])
+    task.create_spaces()
+    model = g.get_model(g.config.SettingsConfig().get_config(f"task_modes/{mode}/model"))
+    spec = task.kernel_spec(model, reset_mode=abi.RESET_RANDOM if dr else abi.RESET_FIXED,
+                            randomize_params=dr, max_episode_steps=100_000)
+    n = args.envs_per_gpu
+    cfg = abi.config_struct(model, spec, num_envs=n, env_offset=rank * n, seed=args.seed,
+                            dtype=abi.F64 if args.dtype == "f64" else abi.F32, contact=contact,
+                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters)
+    return cfg, model, spec
+
+
+def algorithmic_bytes_per_env_step(cfg, esz):
+    """HBM bytes one env-step must move (DESIGN.md 'Data layout'): state + per-env parameters in,
+    state + observation + reward + done out; actions are generated on device."""
+    nq, D = cfg.model.nq, cfg.task.obs_dim
+    dr = cfg.task.reset_mode == 1
+    reads = (2 * nq + 2) * esz + 4 + 4 + 1            # q, qd, last action; step / episode counters, pose
+    if dr:
+        reads += (4 * nq + 1) * esz                   # mass scale, damping, friction, mu, gravity
+    writes = (2 * nq + 4) * esz + D * esz + esz + 1 + 4  # q, qd, action history x2; obs; reward; done; steps
+    return reads + writes
+
+
+def cpu_baseline(args, cfg):
+    """The CPU oracle (same algorithm, scalar fp64 C port) on the host cores: reported baseline."""
+    import copy
+    from oracle import oracle_py
+    oracle_py.build()
+    cores = min(os.cpu_count() or 1, 64)
+    cfg2 = copy.copy(cfg)
+    cfg2.num_envs = args.cpu_envs
+    orc = oracle_py.OracleSim(cfg2, threads=cores)
+    orc.step(None)                                    # warm
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        orc.step(None)
+        steps += 1
+        if time.perf_counter() - t0 >= args.cpu_seconds:
+            break
+    dt = time.perf_counter() - t0
+    orc.close()
+    return {"value": steps * args.cpu_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} env-steps x {args.cpu_envs} envs of the same workload, OpenMP over envs, {dt:.1f} s"}
+
+
+def load_traffic():
+    """HBM traffic per launch from separate rocprofv3 --pmc passes (profiles/), if recorded."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--pgs-iters", type=int, default=20)
+    ap.add_argument("--pgs-normal-iters", type=int, default=8)
+    ap.add_argument("--cpu-envs", type=int, default=2048)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = 4096 if args.workload == "C2" else 65536
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # started without a launcher: become the launcher (child processes; nothing here touched the GPU)
+        port = os.environ.get("MASTER_PORT", "29511")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    from gym_os2r_amd.sim import HipSim
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the stepper has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg, model, spec = build_config(args, rank, world)
+    sim = HipSim(cfg, device=f"cuda:{local_rank}")
+    esz = 8 if args.dtype == "f64" else 4
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.bench_steps(max(args.warmup, 1)) if args.warmup > 0 else None
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = sim.bench_steps(args.steps)           # K launches, HIP events on the launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    total_envs = args.envs_per_gpu * world
+    value = total_envs * args.steps / elapsed
+    if rank == 0:
+        per_launch_s = kernel_ms * 1e-3 / args.steps
+        bytes_launch = algorithmic_bytes_per_env_step(cfg, esz) * args.envs_per_gpu
+        achieved = bytes_launch / per_launch_s / 1e9
+        traffic = load_traffic()
+        out = {
+            "metric": "env-steps/sec (aggregate) monopod balance task",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}",
+                       "envs_per_gpu": args.envs_per_gpu, "total_envs": total_envs, "task_mode": WORKLOADS[args.workload][0],
+                       "substeps": int(cfg.substeps), "dt": float(cfg.dt), "pgs_sweeps": [int(cfg.pgs_normal_iters), int(cfg.pgs_iters)],
+                       "contact": bool(cfg.contact), "domain_randomisation": WORKLOADS[args.workload][3],
+                       "actions": "U(-1,1) Philox on device", "sharding": f"envs x{world}, no step-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "kernel_ms_per_launch": per_launch_s * 1e3,
+                         "note": "ALU-bound path: see roofline_valu"},
+        }
+        flops = None
+        fp = os.path.join(ROOT, "profiles", "flops.json")
+        if os.path.exists(fp):
+            with open(fp) as f:
+                flops = json.load(f).get(f"{args.workload}_{args.dtype}")
+        if flops:
+            tf = flops["flops_per_env_step"] * args.envs_per_gpu / per_launch_s / 1e12
+            peak = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
+            out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                                    "frac": tf / peak, "flops_per_env_step": flops["flops_per_env_step"],
+                                    "source": flops.get("source")}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cfg)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

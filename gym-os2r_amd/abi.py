@@ -103,6 +103,7 @@ class Os2rConfig(C.Structure):
         ("dt", C.c_double),
         ("contact", C.c_int32),
         ("pgs_iters", C.c_int32),
+        ("pgs_normal_iters", C.c_int32),
         ("auto_reset", C.c_int32),
         ("erp", C.c_double),
         ("max_erv", C.c_double),
@@ -189,7 +190,7 @@ def task_struct(t: Mapping) -> Os2rTaskSpec:
 
 def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = F64,
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
-                  dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20,
+                  dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 8,
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3) -> Os2rConfig:
     c = Os2rConfig()
     c.abi_version = ABI_VERSION
@@ -202,6 +203,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     c.dt = float(dt)
     c.contact = 1 if contact else 0
     c.pgs_iters = int(pgs_iters)
+    c.pgs_normal_iters = int(pgs_normal_iters)
     c.auto_reset = 1 if auto_reset else 0
     c.erp = float(erp)
     c.max_erv = float(max_erv)

@@ -20,7 +20,8 @@
 //   5. ground contact: per body, the penetration-weighted centroid of its
 //      collision candidate points gives one frictional point contact
 //   6. projected Gauss-Seidel on the velocities over [contact rows, joint
-//      Coulomb friction rows], fixed sweep count, cold start
+//      Coulomb friction rows], fixed sweep counts, cold start: a normal-only phase
+//      fixes the friction box bounds, then all rows (a convex boxed QP)
 //   7. q += dt*v  (semi-implicit Euler)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -91,6 +92,7 @@ struct StepArgs {
   unsigned long long step_count;
   int substeps;
   int pgs_iters;
+  int pgs_normal_iters;
   int auto_reset;
   T dt, erp, max_erv;
   // state, SoA
@@ -256,7 +258,7 @@ struct Params<T, NQ, true> {
 template <typename T, int NQ, unsigned CMASK, bool DR>
 __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, const Params<T, NQ, DR>& par,
                                         T (&q)[NQ], T (&qd)[NQ], T tau_hip, T tau_knee, T dt, T erp,
-                                        T max_erv, int pgs_iters) {
+                                        T max_erv, int pgs_iters, int pgs_normal_iters) {
   // ---- 1. joint rotations R_i = Rfix_i * Rot(axis_i, q_i) (child orientation in parent) ----
   T R[NQ][9];
 #pragma unroll
@@ -541,53 +543,40 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
 #pragma unroll
   for (int j = 0; j < NQ; ++j) fb[j] = par.friction(j) * dt;
 
-  for (int it = 0; it < pgs_iters; ++it) {
+  // Phase 1 (pgs_normal_iters sweeps): normal rows and joint-friction rows only; its normal
+  // impulses fix the tangential box bounds +-mu*lambda_n.  Phase 2 (pgs_iters sweeps): all rows
+  // with those fixed bounds -- a boxed LCP with a symmetric PSD matrix, i.e. a convex QP with a
+  // unique velocity solution.  pgs_normal_iters == 0 selects the coupled pyramid (bounds follow
+  // the current normal impulse inside the sweep), which is ill-posed for a slender leg sliding
+  // at mu ~ 1 (Painleve) and is kept for experiments only.
+  auto normal_row = [&](int b) {
+    T res = -erv[b];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (!((CMASK >> b) & 1u)) continue;
-      if (!wave_act[b]) continue;
-      const bool on = act[b];
-      // normal row: lambda >= 0, target velocity erv
-      {
-        T res = -erv[b];
+    for (int j = 0; j < NQ; ++j)
+      if (j <= b) res += Jn[b][j] * vs[j];
+    T lam = ln[b] - res / dn[b];
+    lam = lam < T(0) ? T(0) : lam;
+    lam = (act[b] && dn[b] > T(0)) ? lam : ln[b];
+    const T dl = lam - ln[b];
+    ln[b] = lam;
 #pragma unroll
-        for (int j = 0; j <= b; ++j) res += Jn[b][j] * vs[j];
-        T lam = ln[b] - res / dn[b];
-        lam = lam < T(0) ? T(0) : lam;
-        lam = (on && dn[b] > T(0)) ? lam : ln[b];
-        const T dl = lam - ln[b];
-        ln[b] = lam;
+    for (int j = 0; j < NQ; ++j) vs[j] += Tn[b][j] * dl;
+  };
+  auto tangent_row = [&](int b, const T (&J)[NB][NQ], const T (&Tr)[NB][NQ], T d, T& l, T lim) {
+    T res = 0;
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) vs[j] += Tn[b][j] * dl;
-      }
-      const T lim = par.mu(b) * ln[b];
-      {
-        T res = 0;
+    for (int j = 0; j < NQ; ++j)
+      if (j <= b) res += J[b][j] * vs[j];
+    T lam = l - res / d;
+    lam = lam < -lim ? -lim : lam;
+    lam = lam > lim ? lim : lam;
+    lam = (act[b] && d > T(0)) ? lam : l;
+    const T dl = lam - l;
+    l = lam;
 #pragma unroll
-        for (int j = 0; j <= b; ++j) res += Jx[b][j] * vs[j];
-        T lam = lx[b] - res / dx[b];
-        lam = lam < -lim ? -lim : lam;
-        lam = lam > lim ? lim : lam;
-        lam = (on && dx[b] > T(0)) ? lam : lx[b];
-        const T dl = lam - lx[b];
-        lx[b] = lam;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) vs[j] += Tx[b][j] * dl;
-      }
-      {
-        T res = 0;
-#pragma unroll
-        for (int j = 0; j <= b; ++j) res += Jy[b][j] * vs[j];
-        T lam = ly[b] - res / dy[b];
-        lam = lam < -lim ? -lim : lam;
-        lam = lam > lim ? lim : lam;
-        lam = (on && dy[b] > T(0)) ? lam : ly[b];
-        const T dl = lam - ly[b];
-        ly[b] = lam;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) vs[j] += Ty[b][j] * dl;
-      }
-    }
+    for (int j = 0; j < NQ; ++j) vs[j] += Tr[b][j] * dl;
+  };
+  auto joint_rows = [&]() {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       // joint Coulomb friction row: J = e_j, T = Minv[:, j], d = Minv[j][j]
@@ -600,6 +589,30 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
 #pragma unroll
       for (int i = 0; i < NQ; ++i) vs[i] += Mi[i][j] * dl;
     }
+  };
+  const bool fixed_box = pgs_normal_iters > 0;
+  for (int it = 0; it < pgs_normal_iters; ++it) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (wave_act[b]) normal_row(b);
+    }
+    joint_rows();
+  }
+  T limfix[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) limfix[b] = par.mu(b) * ln[b];
+  for (int it = 0; it < pgs_iters; ++it) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (!wave_act[b]) continue;
+      normal_row(b);
+      const T lim = fixed_box ? limfix[b] : par.mu(b) * ln[b];
+      tangent_row(b, Jx, Tx, dx[b], lx[b], lim);
+      tangent_row(b, Jy, Ty, dy[b], ly[b], lim);
+    }
+    joint_rows();
   }
 
   // ---- 7. semi-implicit Euler ----

@@ -150,7 +150,9 @@ typedef struct Os2rConfig {
   int32_t substeps;        /* physics_rate/agent_rate = 10 (runtimes/gazebo_runtime.py:46)   */
   double dt;               /* 1/physics_rate = 1e-4 s                                        */
   int32_t contact;         /* 0: ground contact off (bring-up config C2), 1: on              */
-  int32_t pgs_iters;       /* projected Gauss-Seidel sweeps per substep                      */
+  int32_t pgs_iters;       /* projected Gauss-Seidel sweeps per substep over all rows        */
+  int32_t pgs_normal_iters;/* preceding sweeps over normal + joint-friction rows that fix    */
+                           /*   the tangential bounds (0: coupled pyramid)    */
   int32_t auto_reset;      /* SubprocVecEnv semantics (common/vec_env/subproc_vec_env.py:15) */
   double erp;              /* contact error-reduction parameter                              */
   double max_erv;          /* cap on the error-reduction velocity [m/s]                      */

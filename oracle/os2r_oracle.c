@@ -500,21 +500,33 @@ static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, doubl
     double s = 0; for (int j = 0; j < n; ++j) s += R->J[j] * R->T[j];
     R->d = s;
   }
-  /* projected Gauss-Seidel on the velocities, fixed sweep count, cold start */
-  for (int it = 0; it < cfg->pgs_iters; ++it) {
-    for (int r = 0; r < nr; ++r) {
-      Row* R = &rows[r];
-      if (!(R->d > 0.0)) continue;
-      double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
-      double lam = R->lambda - res / R->d, lo, hi;
-      if (R->kind == 0) { lo = 0.0; hi = INFINITY; }
-      else if (R->kind == 1) { hi = R->bound * rows[R->normal_row].lambda; lo = -hi; }
-      else { hi = R->bound; lo = -hi; }
-      if (lam < lo) lam = lo;
-      if (lam > hi) lam = hi;
-      double dl = lam - R->lambda;
-      R->lambda = lam;
-      for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
+  /* Projected Gauss-Seidel on the velocities, fixed sweep counts, cold start.
+   * Phase 1 (pgs_normal_iters sweeps): normal rows and joint-friction rows only; its normal
+   * impulses fix the tangential box bounds +-mu*lambda_n.  Phase 2 (pgs_iters sweeps): all rows
+   * with those fixed bounds -- a boxed LCP with a symmetric PSD matrix, i.e. a convex QP with a
+   * unique velocity solution.  (With pgs_normal_iters == 0 the bounds follow the current normal
+   * impulse inside the sweep, the classical coupled pyramid, which is ill-posed for a slender
+   * leg sliding at mu ~ 1: Painleve's paradox.) */
+  for (int phase = 0; phase < 2; ++phase) {
+    const int sweeps = phase == 0 ? cfg->pgs_normal_iters : cfg->pgs_iters;
+    if (phase == 1 && cfg->pgs_normal_iters > 0)
+      for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
+    for (int it = 0; it < sweeps; ++it) {
+      for (int r = 0; r < nr; ++r) {
+        Row* R = &rows[r];
+        if (!(R->d > 0.0)) continue;
+        if (phase == 0 && R->kind == 1) continue;
+        double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
+        double lam = R->lambda - res / R->d, lo, hi;
+        if (R->kind == 0) { lo = 0.0; hi = INFINITY; }
+        else if (R->kind == 1) { hi = cfg->pgs_normal_iters > 0 ? R->bound : R->bound * rows[R->normal_row].lambda; lo = -hi; }
+        else { hi = R->bound; lo = -hi; }
+        if (lam < lo) lam = lo;
+        if (lam > hi) lam = hi;
+        double dl = lam - R->lambda;
+        R->lambda = lam;
+        for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
+      }
     }
   }
   for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += dt * v[i]; }
