@@ -107,6 +107,7 @@ class Os2rConfig(C.Structure):
         ("auto_reset", C.c_int32),
         ("erp", C.c_double),
         ("max_erv", C.c_double),
+        ("contact_margin", C.c_double),
         ("model", Os2rModel),
         ("task", Os2rTaskSpec),
     ]
@@ -191,7 +192,8 @@ def task_struct(t: Mapping) -> Os2rTaskSpec:
 def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = F64,
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
                   dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 8,
-                  auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3) -> Os2rConfig:
+                  auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
+                  contact_margin: float = 1e-3) -> Os2rConfig:
     c = Os2rConfig()
     c.abi_version = ABI_VERSION
     c.dtype = int(dtype)
@@ -207,6 +209,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     c.auto_reset = 1 if auto_reset else 0
     c.erp = float(erp)
     c.max_erv = float(max_erv)
+    c.contact_margin = float(contact_margin)
     c.model = model_struct(model)
     c.task = task_struct(task)
     return c

@@ -151,6 +151,7 @@ int validate(const Os2rConfig* c, std::string& why) {
   if (c->substeps < 1 || c->substeps > 1000) { why = "substeps out of range"; return 1; }
   if (!(c->dt > 0.0)) { why = "dt must be positive"; return 1; }
   if (c->pgs_iters < 0 || c->pgs_iters > 10000) { why = "pgs_iters out of range"; return 1; }
+  if (!(c->contact_margin >= 0.0)) { why = "contact_margin must be >= 0"; return 1; }
   if (c->pgs_normal_iters < 0 || c->pgs_normal_iters > 10000) { why = "pgs_normal_iters out of range"; return 1; }
   return 0;
 }
@@ -169,7 +170,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.pgs_iters = s->cfg.pgs_iters;
   a.pgs_normal_iters = s->cfg.pgs_normal_iters;
   a.auto_reset = s->cfg.auto_reset;
-  a.dt = (T)s->cfg.dt; a.erp = (T)s->cfg.erp; a.max_erv = (T)s->cfg.max_erv;
+  a.dt = (T)s->cfg.dt; a.erp = (T)s->cfg.erp; a.max_erv = (T)s->cfg.max_erv; a.margin = (T)s->cfg.contact_margin;
   a.q = (T*)s->q; a.qd = (T*)s->qd; a.hist = (T*)s->hist;
   a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;

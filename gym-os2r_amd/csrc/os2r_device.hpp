@@ -17,8 +17,9 @@
 //   3. inverse of the damping-augmented mass matrix from unit-torque sweeps over
 //      the same factorisation (upper triangle only, by symmetry)
 //   4. v* = qd + dt*qdd
-//   5. ground contact: per body, the penetration-weighted centroid of its
-//      collision candidate points gives one frictional point contact
+//   5. ground contact: per body, the centroid of its collision candidate points that are
+//      within `margin` of the ground, weighted by (margin - z), gives one frictional point
+//      contact with a gap-based non-penetration target (v_n >= -gap/dt)
 //   6. projected Gauss-Seidel on the velocities over [contact rows, joint
 //      Coulomb friction rows], fixed sweep counts, cold start: a normal-only phase
 //      fixes the friction box bounds, then all rows (a convex boxed QP)
@@ -94,7 +95,7 @@ struct StepArgs {
   int pgs_iters;
   int pgs_normal_iters;
   int auto_reset;
-  T dt, erp, max_erv;
+  T dt, erp, max_erv, margin;
   // state, SoA
   T* __restrict__ q;         // [nq][N]
   T* __restrict__ qd;        // [nq][N]
@@ -258,7 +259,7 @@ struct Params<T, NQ, true> {
 template <typename T, int NQ, unsigned CMASK, bool DR>
 __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, const Params<T, NQ, DR>& par,
                                         T (&q)[NQ], T (&qd)[NQ], T tau_hip, T tau_knee, T dt, T erp,
-                                        T max_erv, int pgs_iters, int pgs_normal_iters) {
+                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters) {
   // ---- 1. joint rotations R_i = Rfix_i * Rot(axis_i, q_i) (child orientation in parent) ----
   T R[NQ][9];
 #pragma unroll
@@ -497,7 +498,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
       for (int k = k0; k < k1; ++k) {
         const T px = md->cand_p[k][0], py = md->cand_p[k][1], pz = md->cand_p[k][2];
         const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
-        const T wgt = z < T(0) ? -z : T(0);
+        const T wgt = z < margin ? margin - z : T(0);
         W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
       }
       act[b] = W > T(0);
@@ -506,9 +507,11 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
         const T iw = act[b] ? T(1) / W : T(0);
         const V3<T> pc = mk(sx * iw, sy * iw, sz * iw);
         const V3<T> pw = rmul(Rw, pc) + jo[b];
-        const T depth = -pw.z;
-        const T e = erp * depth / dt;
-        erv[b] = e > max_erv ? max_erv : e;
+        // gap-based non-penetration (Stewart-Trinkle): an open gap may close within the step,
+        // a penetration is pushed out at the capped error-reduction velocity
+        const T gap = pw.z;
+        const T e = erp * (-gap) / dt;
+        erv[b] = gap >= T(0) ? -gap / dt : (e > max_erv ? max_erv : e);
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
           if (j <= b) {

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   }
 
   for (int s = 0; s < A.substeps; ++s)  // runtimes/gazebo_runtime.py:70-77
-    substep<T, NQ, CMASK, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.pgs_iters, A.pgs_normal_iters);
+    substep<T, NQ, CMASK, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters);
 
   bool bad = false;
 #pragma unroll

@@ -156,6 +156,7 @@ typedef struct Os2rConfig {
   int32_t auto_reset;      /* SubprocVecEnv semantics (common/vec_env/subproc_vec_env.py:15) */
   double erp;              /* contact error-reduction parameter                              */
   double max_erv;          /* cap on the error-reduction velocity [m/s]                      */
+  double contact_margin;   /* candidates closer than this to the ground join the contact [m] */
   Os2rModel model;
   Os2rTaskSpec task;
 } Os2rConfig;

@@ -107,14 +107,14 @@ def dynamics(model_struct, q, qd, tau_full, dt=1e-4, mass_scale=None, damping=No
     return qdd, minv, rw.reshape(n, 3, 3), ow
 
 
-def contact_points(model_struct, rw, ow):
+def contact_points(model_struct, rw, ow, margin=0.0):
     n = model_struct.nq
     rw = np.ascontiguousarray(rw, dtype=np.float64).reshape(n, 9)
     ow = np.ascontiguousarray(ow, dtype=np.float64)
     active = np.zeros(n, dtype=np.int32)
     pw, depth = np.zeros((n, 3)), np.zeros(n)
-    lib().orc_contact_points(C.byref(model_struct), _p(rw), _p(ow), _p(active), _p(pw), _p(depth))
-    return active.astype(bool), pw, depth
+    lib().orc_contact_points(C.byref(model_struct), C.c_double(margin), _p(rw), _p(ow), _p(active), _p(pw), _p(depth))
+    return active.astype(bool), pw, -depth
 
 
 def substep(cfg, q, qd, tau2, mass_scale=None, damping=None, friction=None, mu=None, gravity_z=None):

@@ -424,8 +424,11 @@ void orc_dynamics(const Os2rModel* md, double dt, const double* mass_scale, cons
 typedef struct { double J[OS2R_MAX_DOF], T[OS2R_MAX_DOF], d, target, lambda; int kind, normal_row; double bound; } Row;
 /* kind: 0 normal (lambda>=0), 1 tangential (|lambda|<=mu*lambda_normal), 2 joint friction (|lambda|<=bound) */
 
-void orc_contact_points(const Os2rModel* md, const double (*rw)[9], const double (*ow)[3],
-                        int* active, double (*pw)[3], double* depth) {
+void orc_contact_points(const Os2rModel* md, double margin, const double (*rw)[9], const double (*ow)[3],
+                        int* active, double (*pw)[3], double* gap) {
+  /* Per body: candidates closer than `margin` to the ground plane z=0 (or below it) are weighted
+   * by (margin - z); their weighted centroid is the body's single contact point, `gap` its signed
+   * height (negative = penetration). */
   int k = 0;
   for (int b = 0; b < md->nq; ++b) {
     double W = 0, pl[3] = {0, 0, 0};
@@ -433,14 +436,14 @@ void orc_contact_points(const Os2rModel* md, const double (*rw)[9], const double
     for (; k < md->ncand && md->cand_body[k] == b; ++k) {
       const double* p = md->cand_p[k];
       double z = rw[b][6] * p[0] + rw[b][7] * p[1] + rw[b][8] * p[2] + ow[b][2];
-      double w = z < 0.0 ? -z : 0.0;
+      double w = z < margin ? margin - z : 0.0;
       W += w; pl[0] += w * p[0]; pl[1] += w * p[1]; pl[2] += w * p[2];
     }
     if (W > 0.0) {
       double pc[3] = {pl[0] / W, pl[1] / W, pl[2] / W}, t[3];
       m3_vec(rw[b], pc, t);
       for (int i = 0; i < 3; ++i) pw[b][i] = t[i] + ow[b][i];
-      depth[b] = -pw[b][2];
+      gap[b] = pw[b][2];
       active[b] = 1;
     }
   }
@@ -462,8 +465,8 @@ static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, doubl
   Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   int nr = 0;
   if (cfg->contact) {
-    int active[OS2R_MAX_DOF]; double pw[OS2R_MAX_DOF][3], depth[OS2R_MAX_DOF];
-    orc_contact_points(md, rw, ow, active, pw, depth);
+    int active[OS2R_MAX_DOF]; double pw[OS2R_MAX_DOF][3], gap[OS2R_MAX_DOF];
+    orc_contact_points(md, cfg->contact_margin, rw, ow, active, pw, gap);
     for (int b = 0; b < n; ++b) {
       if (!active[b]) continue;
       double Jp[3][OS2R_MAX_DOF];
@@ -475,8 +478,11 @@ static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, doubl
           Jp[0][j] = cr[0]; Jp[1][j] = cr[1]; Jp[2][j] = cr[2];
         } else { Jp[0][j] = Jp[1][j] = Jp[2][j] = 0.0; }
       }
-      double erv = cfg->erp * depth[b] / dt;
-      if (erv > cfg->max_erv) erv = cfg->max_erv;
+      /* gap-based non-penetration (Stewart-Trinkle): an open gap may close within the step,
+       * a penetration is pushed out at the capped error-reduction velocity */
+      double erv;
+      if (gap[b] >= 0.0) erv = -gap[b] / dt;
+      else { erv = cfg->erp * (-gap[b]) / dt; if (erv > cfg->max_erv) erv = cfg->max_erv; }
       const int dirs[3] = {2, 0, 1};  /* normal z, then tangents x, y */
       int nrow = nr;
       for (int t = 0; t < 3; ++t) {

@@ -27,8 +27,8 @@ double orc_reward(const Os2rTaskSpec* ts, const double* obs, const double a0[2],
 void orc_dynamics(const Os2rModel* md, double dt, const double* mass_scale, const double* damping,
                   double gravity_z, const double* q, const double* qd, const double* tau_full,
                   double* qdd, double* minv, double* rw, double* ow);
-void orc_contact_points(const Os2rModel* md, const double (*rw)[9], const double (*ow)[3],
-                        int* active, double (*pw)[3], double* depth);
+void orc_contact_points(const Os2rModel* md, double margin, const double (*rw)[9], const double (*ow)[3],
+                        int* active, double (*pw)[3], double* gap);
 void orc_substep(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
                  const double* mu, double gravity_z, double* q, double* qd, const double tau2[2]);
 

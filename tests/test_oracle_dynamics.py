@@ -154,24 +154,29 @@ def test_joint_friction_holds_a_resting_joint(oracle):
 
 def test_dropped_robot_lands_and_does_not_sink(oracle):
     """Reset 'stand' starts with the foot 4.9 cm above the ground (Appendix A.1): it must fall,
-    hit the plane, and stay within the error-reduction band instead of sinking through."""
+    hit the plane and stay within the contact band instead of sinking through; with no actuation
+    contact and friction may only dissipate energy."""
     cfg, _, m = make_config("free_hip", num_envs=1, contact=True)
     ms = cfg.model
     q, qd = STAND5.copy(), np.zeros(5)
-    tip = np.array([0.0, 0.0, -0.1899853])
     zmin, landed = 1.0, False
-    for k in range(4000):
+    e_prev = lr.kinetic(m, q, qd) + lr.potential(m, q, m["gravity_z"])
+    for k in range(12000):
         q, qd = oracle.substep(cfg, q, qd, [0.0, 0.0])
-        if k % 10 == 0:
+        if k % 20 == 0:
             _, _, rw, ow = oracle.dynamics(ms, q, qd, np.zeros(5))
-            active, _, depth = oracle.contact_points(ms, rw, ow)
+            active, _, gap = oracle.contact_points(ms, rw, ow, cfg.contact_margin)
             landed = landed or active.any()
-            assert not active[0] and not active[1] or q[1] < -0.04   # pivot never, boom only when flat
+            assert not active[0]                                  # the pivot can never touch
             lows = [min((ow[b] + rw[b] @ np.array(p))[2] for p, bb in zip(m["cand_p"], m["cand_body"]) if bb == b)
                     for b in range(1, 5)]
             zmin = min(zmin, min(lows))
+        if k % 200 == 199:
+            e = lr.kinetic(m, q, qd) + lr.potential(m, q, m["gravity_z"])
+            assert e <= e_prev + 1e-5, (k, e, e_prev)
+            e_prev = e
     assert landed
     assert zmin > -2e-3, zmin
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd))
-    # the unactuated leg folds and the robot comes to rest on the ground
-    assert np.abs(qd).max() < 0.5 and q[1] < 0.0
+    # the unactuated leg folds and the robot ends up lying on the ground, (almost) at rest
+    assert np.abs(qd).max() < 1.0 and q[1] < 0.0
