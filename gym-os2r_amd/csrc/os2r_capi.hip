@@ -25,6 +25,7 @@ struct SimBase {
   std::string err;
   int nq = 0, D = 0;
   unsigned cmask = 0;
+  int ax0 = -1;  // axis of joint 0 when every later joint turns about x, else -1 (generic kernel)
   bool dr = false;
   size_t esz = 8;
   unsigned long long step_count = 0;
@@ -58,7 +59,9 @@ namespace {
   } while (0)
 
 template <typename T>
-void fill_model(const Os2rModel& m, DevModel<T>& d) {
+void fill_model(const Os2rModel& m_in, bool contact, DevModel<T>& d) {
+  Os2rModel m = m_in;
+  if (!contact) m.ncand = 0;  // contact off: no candidates reach the kernels, whichever instantiation runs
   std::memset(&d, 0, sizeof(d));
   d.nq = m.nq;
   for (int i = 0; i < OS2R_MAX_DOF; ++i) {
@@ -192,7 +195,7 @@ template <typename T>
 int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* done, void* term, hipStream_t st) {
   StepArgs<T> a = make_args<T>(s);
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
-  if (Launcher<T>::step(s->nq, s->cmask, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
+  if (Launcher<T>::step(s->nq, s->cmask, s->dr, s->ax0, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
   HIP_TRY(s, hipGetLastError());
   s->step_count += 1;
   return OS2R_OK;
@@ -275,6 +278,9 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   // parameter arrays are read per lane only when something can make them differ per env:
   // the randomising reset mode, or a later os2r_set_params (which flips this on)
   s->dr = cfg->task.reset_mode == OS2R_RESET_RANDOM;
+  s->ax0 = cfg->model.axis[0];
+  for (int i = 1; i < cfg->model.nq; ++i)
+    if (cfg->model.axis[i] != 0) s->ax0 = -1;
   s->cmask = 0;
   if (cfg->contact)
     for (int k = 0; k < cfg->model.ncand; ++k) s->cmask |= 1u << cfg->model.cand_body[k];
@@ -298,14 +304,14 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   if ((rc = dev_alloc(s, (void**)&s->b_done, N))) return fail(rc);
   if (cfg->dtype == OS2R_F64) {
     DevModel<double> hm; DevTask<double> ht;
-    fill_model(cfg->model, hm); fill_task(*cfg, ht);
+    fill_model(cfg->model, cfg->contact != 0, hm); fill_task(*cfg, ht);
     if ((rc = dev_alloc(s, &s->model_d, sizeof(hm)))) return fail(rc);
     if ((rc = dev_alloc(s, &s->task_d, sizeof(ht)))) return fail(rc);
     if (hipMemcpy(s->model_d, &hm, sizeof(hm), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(s->task_d, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess) { s->err = "model upload failed"; return fail(OS2R_ERR_HIP); }
   } else {
     DevModel<float> hm; DevTask<float> ht;
-    fill_model(cfg->model, hm); fill_task(*cfg, ht);
+    fill_model(cfg->model, cfg->contact != 0, hm); fill_task(*cfg, ht);
     if ((rc = dev_alloc(s, &s->model_d, sizeof(hm)))) return fail(rc);
     if ((rc = dev_alloc(s, &s->task_d, sizeof(ht)))) return fail(rc);
     if (hipMemcpy(s->model_d, &hm, sizeof(hm), hipMemcpyHostToDevice) != hipSuccess ||

@@ -83,6 +83,15 @@ struct DevTask {
   double nominal_damping[OS2R_MAX_DOF];
 };
 
+// The uniform structs are never written while a kernel runs.  Reading them through
+// constant-address-space pointers tells the compiler exactly that, so every access becomes a
+// scalar load (s_load -> SGPR operand) instead of a per-lane vector load + v_readfirstlane.
+#define OS2R_CONST __attribute__((address_space(4)))
+template <typename T> using ModelPtr = const OS2R_CONST DevModel<T>*;
+template <typename T> using TaskPtr = const OS2R_CONST DevTask<T>*;
+template <typename T> __device__ __forceinline__ ModelPtr<T> as_const(const DevModel<T>* p) { return (ModelPtr<T>)p; }
+template <typename T> __device__ __forceinline__ TaskPtr<T> as_const(const DevTask<T>* p) { return (TaskPtr<T>)p; }
+
 template <typename T>
 struct StepArgs {
   const DevModel<T>* __restrict__ model;
@@ -235,7 +244,7 @@ template <typename T, int NQ, bool DR>
 struct Params;
 template <typename T, int NQ>
 struct Params<T, NQ, false> {
-  const DevModel<T>* m;
+  ModelPtr<T> m;
   __device__ __forceinline__ T mass(int i) const { return m->mass[i]; }
   __device__ __forceinline__ T damping(int i) const { return m->damping[i]; }
   __device__ __forceinline__ T friction(int i) const { return m->friction[i]; }
@@ -244,7 +253,7 @@ struct Params<T, NQ, false> {
 };
 template <typename T, int NQ>
 struct Params<T, NQ, true> {
-  const DevModel<T>* m;
+  ModelPtr<T> m;
   T ms[NQ], dm[NQ], fr[NQ], mu_[NQ], g;
   __device__ __forceinline__ T mass(int i) const { return m->mass[i] * ms[i]; }
   __device__ __forceinline__ T damping(int i) const { return dm[i]; }
@@ -256,8 +265,17 @@ struct Params<T, NQ, true> {
 // ----------------------------------------------------------------------------------------
 // one physics iteration
 // ----------------------------------------------------------------------------------------
-template <typename T, int NQ, unsigned CMASK, bool DR>
-__device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, const Params<T, NQ, DR>& par,
+// Joint axes: AX0 >= 0 fixes joint 0 to that axis and every later joint to x at compile time
+// (the reference's four URDF variants: yaw about z or none, then x-axis joints); AX0 < 0 reads
+// the axes from the model (any serial chain of x/y/z joints).
+template <int AX0, typename T>
+__device__ __forceinline__ int axis_of(ModelPtr<T> md, int i) {
+  if constexpr (AX0 >= 0) return i == 0 ? AX0 : 0;
+  else return md->axis[i];
+}
+
+template <typename T, int NQ, unsigned CMASK, bool DR, int AX0>
+__device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>& par,
                                         T (&q)[NQ], T (&qd)[NQ], T tau_hip, T tau_knee, T dt, T erp,
                                         T max_erv, T margin, int pgs_iters, int pgs_normal_iters) {
   // ---- 1. joint rotations R_i = Rfix_i * Rot(axis_i, q_i) (child orientation in parent) ----
@@ -266,8 +284,8 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
   for (int i = 0; i < NQ; ++i) {
     T s, c;
     sincos_t(q[i], s, c);
-    const T* F = md->rfix[i];
-    const int ax = md->axis[i];
+    const OS2R_CONST T* F = md->rfix[i];
+    const int ax = axis_of<AX0>(md, i);
     // columns a, b of F rotate into each other; column ax stays
     const int ca = ax == 0 ? 1 : (ax == 1 ? 2 : 0);
     const int cb = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
@@ -292,7 +310,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
       w[i] = rtmul(R[i], w[i - 1]);
       v[i] = rtmul(R[i], v[i - 1] + cross(w[i - 1], r));
     }
-    add_comp(w[i], md->axis[i], qd[i]);
+    add_comp(w[i], axis_of<AX0>(md, i), qd[i]);
   }
 
   // ---- 2b. articulated inertias and bias forces, inward ----
@@ -302,7 +320,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
   V3<T> pn, pf;          // children's bias force [moment; force]
 #pragma unroll
   for (int i = NQ - 1; i >= 0; --i) {
-    const int ax = md->axis[i];
+    const int ax = axis_of<AX0>(md, i);
     // rigid-body inertia of body i about its frame origin
     const T m = par.mass(i);
     const V3<T> cm = mk(md->com[i][0], md->com[i][1], md->com[i][2]);
@@ -410,7 +428,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
     V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, -par.gravity());
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int ax = md->axis[i];
+      const int ax = axis_of<AX0>(md, i);
       const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
       V3<T> sq = mk<T>(0, 0, 0);
       add_comp(sq, ax, qd[i]);
@@ -437,7 +455,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
       const V3<T> r = mk(md->rpos[i + 1][0], md->rpos[i + 1][1], md->rpos[i + 1][2]);
       const V3<T> f = rmul(R[i + 1], pf_);
       const V3<T> n = rmul(R[i + 1], pn_) + cross(r, f);
-      uk[i] = -comp(n, md->axis[i]);
+      uk[i] = -comp(n, axis_of<AX0>(md, i));
       const T s = uk[i] * Dinv[i];
       pn_ = n + s * Ua[i];
       pf_ = f + s * Ul[i];
@@ -454,7 +472,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
       const T x = (uk[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
       Mi[i][k] = x;
       Mi[k][i] = x;
-      add_comp(aa, md->axis[i], x);
+      add_comp(aa, axis_of<AX0>(md, i), x);
     }
   }
 
@@ -463,7 +481,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
   constexpr int NB = NQ;
   T Jn[NB][NQ], Jx[NB][NQ], Jy[NB][NQ];  // Jacobian rows: normal z, tangents x, y
   T Tn[NB][NQ], Tx[NB][NQ], Ty[NB][NQ];  // Minv * J^T
-  T dn[NB], dx[NB], dy[NB], erv[NB];
+  T dn[NB], dx[NB], dy[NB], erv[NB];  // dn/dx/dy: reciprocal of J Minv J^T per row (0: row off)
   bool act[NB];
   bool wave_act[NB];
 #pragma unroll
@@ -489,7 +507,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rw[k] = n[k];
       }
-      const int ax = md->axis[b];
+      const int ax = axis_of<AX0>(md, b);
       aw[b] = mk(Rw[ax], Rw[3 + ax], Rw[6 + ax]);
       jo[b] = mk(ow[0], ow[1], ow[2]);
       if (!((CMASK >> b) & 1u)) continue;
@@ -531,7 +549,8 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
         }
 #pragma unroll
         for (int j = 0; j <= b; ++j) { sdn += Jn[b][j] * Tn[b][j]; sdx += Jx[b][j] * Tx[b][j]; sdy += Jy[b][j] * Ty[b][j]; }
-        dn[b] = sdn; dx[b] = sdx; dy[b] = sdy;
+        // reciprocals once per iteration of the physics, not once per row update
+        dn[b] = sdn > T(0) ? T(1) / sdn : T(0); dx[b] = sdx > T(0) ? T(1) / sdx : T(0); dy[b] = sdy > T(0) ? T(1) / sdy : T(0);
       }
     }
   }
@@ -542,9 +561,12 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
   for (int b = 0; b < NB; ++b) { ln[b] = 0; lx[b] = 0; ly[b] = 0; }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) lf[j] = 0;
-  T fb[NQ];  // joint friction impulse bound
+  T fb[NQ], imjj[NQ];  // joint friction impulse bound, 1 / Minv[j][j] (0: row off)
 #pragma unroll
-  for (int j = 0; j < NQ; ++j) fb[j] = par.friction(j) * dt;
+  for (int j = 0; j < NQ; ++j) {
+    fb[j] = par.friction(j) * dt;
+    imjj[j] = (fb[j] > T(0) && Mi[j][j] > T(0)) ? T(1) / Mi[j][j] : T(0);
+  }
 
   // Phase 1 (pgs_normal_iters sweeps): normal rows and joint-friction rows only; its normal
   // impulses fix the tangential box bounds +-mu*lambda_n.  Phase 2 (pgs_iters sweeps): all rows
@@ -557,9 +579,9 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
       if (j <= b) res += Jn[b][j] * vs[j];
-    T lam = ln[b] - res / dn[b];
+    T lam = ln[b] - res * dn[b];
     lam = lam < T(0) ? T(0) : lam;
-    lam = (act[b] && dn[b] > T(0)) ? lam : ln[b];
+    lam = act[b] ? lam : ln[b];
     const T dl = lam - ln[b];
     ln[b] = lam;
 #pragma unroll
@@ -570,7 +592,7 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
       if (j <= b) res += J[b][j] * vs[j];
-    T lam = l - res / d;
+    T lam = l - res * d;
     lam = lam < -lim ? -lim : lam;
     lam = lam > lim ? lim : lam;
     lam = (act[b] && d > T(0)) ? lam : l;
@@ -583,10 +605,10 @@ __device__ __forceinline__ void substep(const DevModel<T>* __restrict__ md, cons
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       // joint Coulomb friction row: J = e_j, T = Minv[:, j], d = Minv[j][j]
-      T lam = lf[j] - vs[j] / Mi[j][j];
+      T lam = lf[j] - vs[j] * imjj[j];
       lam = lam < -fb[j] ? -fb[j] : lam;
       lam = lam > fb[j] ? fb[j] : lam;
-      lam = (fb[j] > T(0) && Mi[j][j] > T(0)) ? lam : lf[j];
+      lam = imjj[j] > T(0) ? lam : lf[j];
       const T dl = lam - lf[j];
       lf[j] = lam;
 #pragma unroll

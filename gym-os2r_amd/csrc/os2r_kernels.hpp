@@ -38,7 +38,7 @@ __device__ __forceinline__ T wrap_pi(T x) {
 
 // value before the affine / tanh map, and the observation itself (tasks/monopod.py:238-272)
 template <typename T, int NQ>
-__device__ __forceinline__ void observe(const DevTask<T>* __restrict__ ts, const T (&q)[NQ], const T (&qd)[NQ],
+__device__ __forceinline__ void observe(TaskPtr<T> ts, const T (&q)[NQ], const T (&qd)[NQ],
                                         T h1a, T h1b, T (&obs)[OS2R_MAX_OBS], bool& done) {
 #pragma clang fp contract(off)
   done = false;
@@ -100,7 +100,7 @@ __device__ __forceinline__ T pick_obs(const T (&obs)[OS2R_MAX_OBS], int idx) {
 
 // rewards/__init__.py:66-207.  a0 = actions[0] (just applied), a1 = actions[1] (previous)
 template <typename T>
-__device__ __forceinline__ T reward_of(const DevTask<T>* __restrict__ ts, const T (&obs)[OS2R_MAX_OBS], T a0x, T a0y,
+__device__ __forceinline__ T reward_of(TaskPtr<T> ts, const T (&obs)[OS2R_MAX_OBS], T a0x, T a0y,
                                        T a1x, T a1y) {
 #pragma clang fp contract(off)
   const T nrm = ts->normalized ? T(1) : T(0);
@@ -166,7 +166,7 @@ template <typename T, int NQ, bool DR>
 __device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uint32_t epi, T (&q)[NQ], T (&qd)[NQ],
                                           Params<T, NQ, DR>& par, uint8_t& pose) {
 #pragma clang fp contract(off)
-  const DevTask<T>* __restrict__ ts = A.task;
+  const TaskPtr<T> ts = as_const(A.task);
   const uint32_t genv = (uint32_t)(A.env_offset + e);
   double u0, u1;
   uniform2(A.seed, genv, kStreamReset, epi, 0, u0, u1);
@@ -236,7 +236,7 @@ __device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uin
 
 template <typename T, int NQ, bool DR>
 __device__ __forceinline__ void load_params(const StepArgs<T>& A, long long e, Params<T, NQ, DR>& par) {
-  par.m = A.model;
+  par.m = as_const(A.model);
   if constexpr (DR) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -279,15 +279,15 @@ __device__ __forceinline__ void store_obs_tile(T* __restrict__ dst, const T (&ob
 // ----------------------------------------------------------------------------------------
 // env-step kernel: GazeboRuntime.step (runtimes/gazebo_runtime.py:65-97) for every env
 // ----------------------------------------------------------------------------------------
-template <typename T, int NQ, unsigned CMASK, bool DR>
+template <typename T, int NQ, unsigned CMASK, bool DR, int AX0>
 __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   __shared__ T tile[kWave * OS2R_MAX_OBS];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
   const long long e = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
-  const DevModel<T>* __restrict__ md = A.model;
-  const DevTask<T>* __restrict__ ts = A.task;
+  const ModelPtr<T> md = as_const(A.model);
+  const TaskPtr<T> ts = as_const(A.task);
 
   T q[NQ], qd[NQ];
 #pragma unroll
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   }
 
   for (int s = 0; s < A.substeps; ++s)  // runtimes/gazebo_runtime.py:70-77
-    substep<T, NQ, CMASK, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters);
+    substep<T, NQ, CMASK, DR, AX0>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters);
 
   bool bad = false;
 #pragma unroll
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const StepArgs<T> A) {
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
   const long long e = valid ? e0 + lane : A.N - 1;
-  const DevTask<T>* __restrict__ ts = A.task;
+  const TaskPtr<T> ts = as_const(A.task);
   T q[NQ], qd[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -439,7 +439,7 @@ __global__ void fill_kernel(T* __restrict__ dst, long long n, T value) {
 // launch tables (defined in the per-dtype instantiation units)
 template <typename T>
 struct Launcher {
-  static int step(int nq, unsigned cmask, bool dr, const StepArgs<T>& args, hipStream_t stream);
+  static int step(int nq, unsigned cmask, bool dr, int ax0, const StepArgs<T>& args, hipStream_t stream);
   static int reset(int nq, bool dr, const StepArgs<T>& args, hipStream_t stream);
   static void gravity(T* g, long long N, long long off, unsigned long long seed, double mean, double std_, hipStream_t s);
   static void fill(T* dst, long long n, T value, hipStream_t s);

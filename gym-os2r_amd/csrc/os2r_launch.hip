@@ -4,15 +4,15 @@
 namespace os2r {
 
 template <typename R, int N_>
-int step_unit(unsigned cmask, bool dr, const StepArgs<R>& a, hipStream_t s);
+int step_unit(unsigned cmask, bool dr, bool std_axes, const StepArgs<R>& a, hipStream_t s);
 template <typename R, int N_>
 int reset_unit(bool dr, const StepArgs<R>& a, hipStream_t s);
 
 #define OS2R_DECL(R)                                                                        \
-  template <> int step_unit<R, 2>(unsigned, bool, const StepArgs<R>&, hipStream_t);          \
-  template <> int step_unit<R, 3>(unsigned, bool, const StepArgs<R>&, hipStream_t);          \
-  template <> int step_unit<R, 4>(unsigned, bool, const StepArgs<R>&, hipStream_t);          \
-  template <> int step_unit<R, 5>(unsigned, bool, const StepArgs<R>&, hipStream_t);          \
+  template <> int step_unit<R, 2>(unsigned, bool, bool, const StepArgs<R>&, hipStream_t);          \
+  template <> int step_unit<R, 3>(unsigned, bool, bool, const StepArgs<R>&, hipStream_t);          \
+  template <> int step_unit<R, 4>(unsigned, bool, bool, const StepArgs<R>&, hipStream_t);          \
+  template <> int step_unit<R, 5>(unsigned, bool, bool, const StepArgs<R>&, hipStream_t);          \
   template <> int reset_unit<R, 2>(bool, const StepArgs<R>&, hipStream_t);                   \
   template <> int reset_unit<R, 3>(bool, const StepArgs<R>&, hipStream_t);                   \
   template <> int reset_unit<R, 4>(bool, const StepArgs<R>&, hipStream_t);                   \
@@ -21,12 +21,12 @@ OS2R_DECL(float)
 OS2R_DECL(double)
 
 template <typename T>
-int Launcher<T>::step(int nq, unsigned cmask, bool dr, const StepArgs<T>& a, hipStream_t s) {
+int Launcher<T>::step(int nq, unsigned cmask, bool dr, int ax0, const StepArgs<T>& a, hipStream_t s) {
   switch (nq) {
-    case 2: return step_unit<T, 2>(cmask, dr, a, s);
-    case 3: return step_unit<T, 3>(cmask, dr, a, s);
-    case 4: return step_unit<T, 4>(cmask, dr, a, s);
-    case 5: return step_unit<T, 5>(cmask, dr, a, s);
+    case 2: return step_unit<T, 2>(cmask, dr, ax0 == (2 >= 4 ? 2 : 0), a, s);
+    case 3: return step_unit<T, 3>(cmask, dr, ax0 == (3 >= 4 ? 2 : 0), a, s);
+    case 4: return step_unit<T, 4>(cmask, dr, ax0 == (4 >= 4 ? 2 : 0), a, s);
+    case 5: return step_unit<T, 5>(cmask, dr, ax0 == (5 >= 4 ? 2 : 0), a, s);
     default: return 1;
   }
 }
