@@ -26,3 +26,7 @@ def get_model(name: str) -> dict:
     if name not in models:
         raise KeyError(f"unknown monopod model {name!r}; available: {sorted(models)}")
     return models[name]
+
+
+from . import common, models, randomizers, registry, runtimes, scenario  # noqa: F401,E402
+from .registry import REGISTRY, make  # noqa: F401,E402

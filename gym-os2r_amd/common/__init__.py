@@ -1,0 +1,18 @@
+"""Factories with the reference's names (gym_os2r/common/__init__.py:12-53).  ``make_mp_envs``
+returns one batched VecEnv on one GPU instead of ``nenvs`` OS processes."""
+import functools
+
+from ..registry import make
+from .vec_env import HipVecEnv
+
+
+def make_env_from_id(env_id: str, **kwargs):
+    return make(env_id, **kwargs)
+
+
+def make_mp_envs(env_id, nenvs, seed, randomizer, start_idx=0, **kwargs):
+    """``nenvs`` environments with per-env RNG streams keyed by ``seed`` and the global env index
+    ``start_idx + i`` (the reference seeds process ``i`` with ``seed + start_idx + i``)."""
+    make_env = functools.partial(make_env_from_id, env_id=env_id, num_envs=nenvs, seed=seed,
+                                 env_offset=start_idx, **kwargs)
+    return HipVecEnv(randomizer(env=make_env))

@@ -1,0 +1,153 @@
+"""Batched gym.Env-shaped runtime on the HIP stepper.
+
+Drop-in for ``gym_os2r.runtimes.gazebo_runtime.GazeboRuntime`` (runtimes/gazebo_runtime.py:12-123)
+for the env-step path: same constructor kwargs (``task_cls, agent_rate, physics_rate,
+real_time_factor`` + the task kwargs ``task_mode, reward_class, reset_positions``), same
+``step / reset / seed / close / render`` surface, ``.task``, ``.action_space``,
+``.observation_space``.  What changes is the batch dimension: one runtime owns ``num_envs``
+environments on one GPU and ``step`` takes ``actions[N, 2]`` and returns
+``(obs[N, D], reward[N], done[N], infos)`` with the reference's SubprocVecEnv semantics
+(common/vec_env/subproc_vec_env.py:15-21): a done environment is reset inside the same kernel
+launch, ``obs`` then holds its first observation of the new episode and
+``infos['terminal_observation']`` the last one of the old.
+
+Everything stays on the device (torch tensors); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .. import abi, get_model
+from ..config import SettingsConfig
+
+
+class BatchedInfo(dict):
+    """Info of one batched step.  Dict of tensors; ``as_list()`` builds the per-env list of dicts
+    a SubprocVecEnv consumer expects (use for small N only)."""
+
+    def as_list(self, pose_names):
+        n = int(self["done_flags"].shape[0])
+        flags = self["done_flags"].cpu().numpy()
+        poses = self["reset_orientation_id"].cpu().numpy()
+        term = self["terminal_observation"].cpu().numpy() if "terminal_observation" in self else None
+        out = []
+        for i in range(n):
+            d = {"reset_orientation": pose_names[int(poses[i])]}
+            if flags[i] & abi.TRUNCATED_BIT:
+                d["TimeLimit.truncated"] = not bool(flags[i] & abi.DONE_BIT)
+            if flags[i] and term is not None:
+                d["terminal_observation"] = term[i]
+            out.append(d)
+        return out
+
+
+class HipRuntime:
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, task_cls: type, agent_rate: float, physics_rate: float,
+                 real_time_factor: float = float(np.finfo(np.float32).max), *,
+                 num_envs: int = 1, device=None, seed: int = 0, dtype: str = "f64",
+                 contact: bool = True, max_episode_steps: int = 0, env_offset: int = 0,
+                 pgs_iters: int = 20, pgs_normal_iters: int = 8, auto_reset: bool = True,
+                 physics_engine=None, world: Optional[str] = None, **kwargs):
+        steps = physics_rate / agent_rate
+        if steps != int(steps):
+            import warnings
+            warnings.warn(f"Rounding the number of iterations to {int(steps)} from the nominal {steps}")
+        self.num_of_steps_per_run = int(steps)           # runtimes/gazebo_runtime.py:46-55
+        self._physics_rate, self._agent_rate = float(physics_rate), float(agent_rate)
+        self._real_time_factor = real_time_factor        # accepted for signature parity; runs flat out
+        self.task = task_cls(agent_rate=agent_rate, **kwargs)
+        self.action_space, self.observation_space = self.task.create_spaces()
+        self.task.action_space, self.task.observation_space = self.action_space, self.observation_space
+        self.num_envs = int(num_envs)
+        self._opts = dict(device=device, seed=int(seed), dtype=dtype, contact=bool(contact),
+                          max_episode_steps=int(max_episode_steps), env_offset=int(env_offset),
+                          pgs_iters=int(pgs_iters), pgs_normal_iters=int(pgs_normal_iters),
+                          auto_reset=bool(auto_reset))
+        # set by the randomizer wrappers before the first reset (randomizers/*.py)
+        self._reset_mode = abi.RESET_FIXED
+        self._randomize_params = False
+        self._sim = None
+        cfg = getattr(self.task, "cfg", None) or SettingsConfig()
+        self.model = dict(get_model(cfg.get_config(f"task_modes/{self.task.task_mode}/model")))
+        self.pose_names = list(cfg.get_config("/resets").keys())
+        self._buffers = None
+
+    # -- configuration hooks ----------------------------------------------------------------
+    def configure_reset(self, reset_mode: int, randomize_params: bool):
+        if self._sim is not None:
+            raise RuntimeError("reset mode must be chosen before the first reset()")
+        self._reset_mode, self._randomize_params = int(reset_mode), bool(randomize_params)
+        if reset_mode == abi.RESET_FIXED:
+            self.model["gravity_z"] = -9.80665
+        return self
+
+    def seed(self, seed=None):
+        if self._sim is not None:
+            raise RuntimeError("seed() must be called before the first reset()")
+        self._opts["seed"] = 0 if seed is None else int(seed)
+        self.action_space.seed(seed)
+        return [seed]
+
+    # -- lifecycle --------------------------------------------------------------------------
+    @property
+    def sim(self):
+        """The device simulator handle (created on first use; raises without GPU / extension)."""
+        if self._sim is None:
+            from ..sim import HipSim
+            o = self._opts
+            spec = self.task.kernel_spec(self.model, reset_mode=self._reset_mode,
+                                         randomize_params=self._randomize_params,
+                                         max_episode_steps=o["max_episode_steps"])
+            cfg = abi.config_struct(self.model, spec, num_envs=self.num_envs,
+                                    dtype=abi.F64 if o["dtype"] == "f64" else abi.F32,
+                                    env_offset=o["env_offset"], seed=o["seed"],
+                                    substeps=self.num_of_steps_per_run, dt=1.0 / self._physics_rate,
+                                    contact=o["contact"], pgs_iters=o["pgs_iters"],
+                                    pgs_normal_iters=o["pgs_normal_iters"], auto_reset=o["auto_reset"])
+            self._sim = HipSim(cfg, device=o["device"])
+        return self._sim
+
+    def reset(self, mask=None):
+        """Reset every environment (or those in ``mask``) and return the observations [N, D]."""
+        first = self._sim is None
+        sim = self.sim
+        if first and mask is None:
+            # os2r_create already performed the initial reset of every environment
+            import torch
+            return sim.reset(torch.zeros(self.num_envs, dtype=torch.uint8, device=sim.device))
+        return sim.reset(mask)
+
+    def step(self, actions):
+        """actions [N, 2] in [-1, 1] -> (obs [N, D], reward [N], done [N] bool, BatchedInfo)."""
+        import torch
+        sim = self.sim
+        a = torch.as_tensor(actions, device=sim.device).to(sim.dtype)
+        if a.dim() == 1 and self.num_envs == 1:
+            a = a.reshape(1, 2)
+        if bool(((a < -1) | (a > 1)).any()):            # gazebo_runtime.py:67-68 warns; the task asserts
+            raise AssertionError("%r invalid: actions must lie in the action space [-1, 1]" % (actions,))
+        obs, rew, flags, term = sim.step(a, want_terminal=True)
+        _, _, pose = sim.episode_info()
+        info = BatchedInfo(done_flags=flags, terminal_observation=term, reset_orientation_id=pose,
+                           truncated=(flags & abi.TRUNCATED_BIT).bool())
+        return obs, rew, flags != 0, info
+
+    def get_state_info(self, obs, actions):
+        """(reward, done) recomputed on the host for one observation (tasks/monopod.py:348-366)."""
+        return self.task.get_state_info(np.asarray(obs, dtype=np.float64), actions)
+
+    def render(self, mode: str = "human", **kwargs):
+        return None                                      # headless: there is no Gazebo GUI to open
+
+    def close(self):
+        if self._sim is not None:
+            self._sim.close()
+            self._sim = None
+
+    @property
+    def unwrapped(self):
+        return self

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory (rocprofv3 CSVs) into one JSON + markdown summary.
+
+Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>
+Counter corrections follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (reported as-is and
+doubled, both are given; this kernel's reads are 8-byte-per-lane SoA loads, uncalibrated width).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def counters(d, kernel_substr):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    kern = sys.argv[3] if len(sys.argv) > 3 else "step_kernel"
+    stats = []
+    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+        stats = list(csv.DictReader(open(f)))
+    trace_rows = []
+    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+        trace_rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+    c, n = counters(src, kern)
+    step = next((r for r in stats if kern in r["Name"]), None)
+    out = {"kernel": step["Name"] if step else None,
+           "calls": int(step["Calls"]) if step else None,
+           "avg_ns": float(step["AverageNs"]) if step else None,
+           "min_ns": float(step["MinNs"]) if step else None,
+           "max_ns": float(step["MaxNs"]) if step else None,
+           "pct_of_gpu_time": float(step["Percentage"]) if step else None,
+           "counters_per_launch": c}
+    if trace_rows:
+        r = trace_rows[0]
+        out["launch"] = {k: r[k] for k in ("Grid_Size_X", "Workgroup_Size_X", "VGPR_Count", "Accum_VGPR_Count",
+                                            "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        out["hbm_bytes_per_launch_raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        out["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+    if "SQ_INSTS_VALU" in c and "SQ_WAVES" in c:
+        out["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst + ".json", "w") as f:
+        json.dump(out, f, indent=1)
+    with open(dst + ".md", "w") as f:
+        f.write(f"# rocprofv3 summary: {os.path.basename(src)}\n\n")
+        f.write("## kernel-trace --stats\n\n| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
+        for r in stats:
+            f.write(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.3f} |\n")
+        if "launch" in out:
+            f.write("\n## launch\n\n" + ", ".join(f"{k}={v}" for k, v in out["launch"].items()) + "\n")
+        f.write("\n## PMC (mean per launch of the step kernel; separate passes)\n\n| counter | value |\n|---|---|\n")
+        for k in sorted(c):
+            f.write(f"| {k} | {c[k]:.6g} |\n")
+        if "hbm_bytes_per_launch" in out:
+            f.write(f"\nHBM bytes per launch: raw (FETCH+WRITE)*1024 = {out['hbm_bytes_per_launch_raw']:.4g}; "
+                    f"with the gfx950 FETCH_SIZE x2 correction = {out['hbm_bytes_per_launch']:.4g}\n")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
