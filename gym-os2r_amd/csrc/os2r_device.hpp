@@ -274,30 +274,46 @@ __device__ __forceinline__ int axis_of(ModelPtr<T> md, int i) {
   else return md->axis[i];
 }
 
+// Opaque copy: a fresh SSA value the optimiser cannot merge with earlier uses.  Used to
+// *re*-compute cheap quantities (a joint rotation is 12 FMAs) instead of holding them in
+// registers across the whole physics iteration: fp64 state is register hungry and anything
+// beyond 512 registers per lane spills to scratch, i.e. to HBM.
+__device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+
+// R_i = Rfix_i * Rot(axis_i, q_i): child orientation in its parent, from (sin q_i, cos q_i)
+template <int AX0, typename T>
+__device__ __forceinline__ void joint_rotation(ModelPtr<T> md, int i, T s_, T c_, T (&R)[9]) {
+  const T s = opaque(s_), c = opaque(c_);
+  const OS2R_CONST T* F = md->rfix[i];
+  const int ax = axis_of<AX0>(md, i);
+  // columns ca, cb of F rotate into each other; column ax stays
+  const int ca = ax == 0 ? 1 : (ax == 1 ? 2 : 0);
+  const int cb = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const T fa = F[3 * r + ca], fb = F[3 * r + cb];
+    R[3 * r + ax] = F[3 * r + ax];
+    R[3 * r + ca] = c * fa + s * fb;
+    R[3 * r + cb] = c * fb - s * fa;
+  }
+}
+
 template <typename T, int NQ, unsigned CMASK, bool DR, int AX0>
 __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>& par,
                                         T (&q)[NQ], T (&qd)[NQ], T tau_hip, T tau_knee, T dt, T erp,
-                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters) {
-  // ---- 1. joint rotations R_i = Rfix_i * Rot(axis_i, q_i) (child orientation in parent) ----
-  T R[NQ][9];
+                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds) {
+#ifdef OS2R_MARK
+  asm volatile("; SEC_1_sincos");
+#endif
+  // ---- 1. sin/cos of the joint angles; rotations are rebuilt from them where needed ----
+  T sn[NQ], cs[NQ];
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    T s, c;
-    sincos_t(q[i], s, c);
-    const OS2R_CONST T* F = md->rfix[i];
-    const int ax = axis_of<AX0>(md, i);
-    // columns a, b of F rotate into each other; column ax stays
-    const int ca = ax == 0 ? 1 : (ax == 1 ? 2 : 0);
-    const int cb = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const T fa = F[3 * r + ca], fb = F[3 * r + cb];
-      R[i][3 * r + ax] = F[3 * r + ax];
-      R[i][3 * r + ca] = c * fa + s * fb;
-      R[i][3 * r + cb] = c * fb - s * fa;
-    }
-  }
+  for (int i = 0; i < NQ; ++i) sincos_t(q[i], sn[i], cs[i]);
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_2a_vel");
+#endif
   // ---- 2a. body velocities (body coordinates), outward ----
   V3<T> w[NQ], v[NQ];
 #pragma unroll
@@ -307,12 +323,17 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
       v[0] = mk<T>(0, 0, 0);
     } else {
       const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
-      w[i] = rtmul(R[i], w[i - 1]);
-      v[i] = rtmul(R[i], v[i - 1] + cross(w[i - 1], r));
+      T Ri[9];
+      joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
+      w[i] = rtmul(Ri, w[i - 1]);
+      v[i] = rtmul(Ri, v[i - 1] + cross(w[i - 1], r));
     }
     add_comp(w[i], axis_of<AX0>(md, i), qd[i]);
   }
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_2b_inward");
+#endif
   // ---- 2b. articulated inertias and bias forces, inward ----
   V3<T> Ua[NQ], Ul[NQ];  // U_i = I^A_i S_i  (angular, linear part)
   T Dinv[NQ], u[NQ];
@@ -388,10 +409,12 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
       const V3<T> paf = pAf + Htc + symmul(Ia.M, cl) + ud * Ul[i];
       // express in the parent frame: rotate by R_i, then shift by r_i
       const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+      T Ri[9];
+      joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
       T Ar[6], Hr[9], Mr[6];
-      rot_sym(R[i], Ia.A, Ar);
-      rot_general(R[i], Ia.H, Hr);
-      rot_sym(R[i], Ia.M, Mr);
+      rot_sym(Ri, Ia.A, Ar);
+      rot_general(Ri, Ia.H, Hr);
+      rot_sym(Ri, Ia.M, Mr);
       const T Mf[9] = {Mr[0], Mr[1], Mr[2], Mr[1], Mr[3], Mr[4], Mr[2], Mr[4], Mr[5]};
       // H'' = Hr + r^ M  (column j: r x M[:,j])
       T Hs[9];
@@ -417,11 +440,14 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
       for (int k = 0; k < 9; ++k) acc.H[k] = Hs[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc.M[k] = Mr[k];
-      pf = rmul(R[i], paf);
-      pn = rmul(R[i], pan) + cross(r, pf);
+      pf = rmul(Ri, paf);
+      pn = rmul(Ri, pan) + cross(r, pf);
     }
   }
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_2c_outward");
+#endif
   // ---- 2c. accelerations, outward; the base accelerates by -g (gravity as a fictitious force) ----
   T vs[NQ];  // predicted velocity v* = qd + dt*qdd
   {
@@ -432,8 +458,10 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
       const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
       V3<T> sq = mk<T>(0, 0, 0);
       add_comp(sq, ax, qd[i]);
-      const V3<T> pa_ = rtmul(R[i], aa);
-      const V3<T> pl_ = rtmul(R[i], al + cross(aa, r));
+      T Ri[9];
+      joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
+      const V3<T> pa_ = rtmul(Ri, aa);
+      const V3<T> pl_ = rtmul(Ri, al + cross(aa, r));
       aa = pa_ + cross(w[i], sq);
       al = pl_ + cross(v[i], sq);
       const T qdd = (u[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
@@ -442,6 +470,9 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     }
   }
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_3_minv");
+#endif
   // ---- 3. inverse of (M + dt*diag(d)): unit-torque sweeps, upper triangle ----
   T Mi[NQ][NQ];
 #pragma unroll
@@ -453,8 +484,10 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     for (int i = k - 1; i >= 0; --i) {
       // bias force of body i+1 expressed in body i
       const V3<T> r = mk(md->rpos[i + 1][0], md->rpos[i + 1][1], md->rpos[i + 1][2]);
-      const V3<T> f = rmul(R[i + 1], pf_);
-      const V3<T> n = rmul(R[i + 1], pn_) + cross(r, f);
+      T Ri[9];
+      joint_rotation<AX0>(md, i + 1, sn[i + 1], cs[i + 1], Ri);
+      const V3<T> f = rmul(Ri, pf_);
+      const V3<T> n = rmul(Ri, pn_) + cross(r, f);
       uk[i] = -comp(n, axis_of<AX0>(md, i));
       const T s = uk[i] * Dinv[i];
       pn_ = n + s * Ua[i];
@@ -465,8 +498,10 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     for (int i = 0; i <= k; ++i) {
       if (i > 0) {
         const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
-        const V3<T> na = rtmul(R[i], aa);
-        al = rtmul(R[i], al + cross(aa, r));
+        T Ri[9];
+        joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
+        const V3<T> na = rtmul(Ri, aa);
+        al = rtmul(Ri, al + cross(aa, r));
         aa = na;
       }
       const T x = (uk[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
@@ -476,11 +511,17 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     }
   }
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_5_contacts");
+#endif
   // ---- 5. ground contact candidates -> one point contact per body ----
   // rows live in registers with static indexing; bodies without candidates compile out (CMASK)
   constexpr int NB = NQ;
   T Jn[NB][NQ], Jx[NB][NQ], Jy[NB][NQ];  // Jacobian rows: normal z, tangents x, y
-  T Tn[NB][NQ], Tx[NB][NQ], Ty[NB][NQ];  // Minv * J^T
+  // Minv * J^T of every row lives in LDS, one 8/4-byte slot per lane per value (slot-major, so a
+  // wave's access is 64 consecutive words: conflict free): Tl(b, row, j)
+  const int lane_ = threadIdx.x;
+  auto Tl = [&](int b, int row, int j) -> T& { return lds[((b * 3 + row) * NQ + j) * kWave + lane_]; };
   T dn[NB], dx[NB], dy[NB], erv[NB];  // dn/dx/dy: reciprocal of J Minv J^T per row (0: row off)
   bool act[NB];
   bool wave_act[NB];
@@ -492,9 +533,11 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const V3<T> r = mk(md->rpos[b][0], md->rpos[b][1], md->rpos[b][2]);
+      T Rb[9];
+      joint_rotation<AX0>(md, b, sn[b], cs[b], Rb);
       if (b == 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rw[k] = R[0][k];
+        for (int k = 0; k < 9; ++k) Rw[k] = Rb[k];
         ow[0] = r.x; ow[1] = r.y; ow[2] = r.z;
       } else {
         const V3<T> t = rmul(Rw, r);
@@ -503,7 +546,7 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) n[3 * i + j] = Rw[3 * i] * R[b][j] + Rw[3 * i + 1] * R[b][3 + j] + Rw[3 * i + 2] * R[b][6 + j];
+          for (int j = 0; j < 3; ++j) n[3 * i + j] = Rw[3 * i] * Rb[j] + Rw[3 * i + 1] * Rb[3 + j] + Rw[3 * i + 2] * Rb[6 + j];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rw[k] = n[k];
       }
@@ -545,16 +588,18 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
           T tn = 0, tx = 0, ty = 0;
 #pragma unroll
           for (int j = 0; j <= b; ++j) { tn += Mi[i][j] * Jn[b][j]; tx += Mi[i][j] * Jx[b][j]; ty += Mi[i][j] * Jy[b][j]; }
-          Tn[b][i] = tn; Tx[b][i] = tx; Ty[b][i] = ty;
+          Tl(b, 0, i) = tn; Tl(b, 1, i) = tx; Tl(b, 2, i) = ty;
+          if (i <= b) { sdn += Jn[b][i] * tn; sdx += Jx[b][i] * tx; sdy += Jy[b][i] * ty; }
         }
-#pragma unroll
-        for (int j = 0; j <= b; ++j) { sdn += Jn[b][j] * Tn[b][j]; sdx += Jx[b][j] * Tx[b][j]; sdy += Jy[b][j] * Ty[b][j]; }
         // reciprocals once per iteration of the physics, not once per row update
         dn[b] = sdn > T(0) ? T(1) / sdn : T(0); dx[b] = sdx > T(0) ? T(1) / sdx : T(0); dy[b] = sdy > T(0) ? T(1) / sdy : T(0);
       }
     }
   }
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_6_pgs");
+#endif
   // ---- 6. projected Gauss-Seidel on the velocities ----
   T ln[NB], lx[NB], ly[NB], lf[NQ];
 #pragma unroll
@@ -585,9 +630,9 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     const T dl = lam - ln[b];
     ln[b] = lam;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) vs[j] += Tn[b][j] * dl;
+    for (int j = 0; j < NQ; ++j) vs[j] += Tl(b, 0, j) * dl;
   };
-  auto tangent_row = [&](int b, const T (&J)[NB][NQ], const T (&Tr)[NB][NQ], T d, T& l, T lim) {
+  auto tangent_row = [&](int b, const T (&J)[NB][NQ], int row, T d, T& l, T lim) {
     T res = 0;
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
@@ -599,7 +644,7 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     const T dl = lam - l;
     l = lam;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) vs[j] += Tr[b][j] * dl;
+    for (int j = 0; j < NQ; ++j) vs[j] += Tl(b, row, j) * dl;
   };
   auto joint_rows = [&]() {
 #pragma unroll
@@ -634,12 +679,15 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
       if (!wave_act[b]) continue;
       normal_row(b);
       const T lim = fixed_box ? limfix[b] : par.mu(b) * ln[b];
-      tangent_row(b, Jx, Tx, dx[b], lx[b], lim);
-      tangent_row(b, Jy, Ty, dy[b], ly[b], lim);
+      tangent_row(b, Jx, 1, dx[b], lx[b], lim);
+      tangent_row(b, Jy, 2, dy[b], ly[b], lim);
     }
     joint_rows();
   }
 
+#ifdef OS2R_MARK
+  asm volatile("; SEC_7_integrate");
+#endif
   // ---- 7. semi-implicit Euler ----
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {

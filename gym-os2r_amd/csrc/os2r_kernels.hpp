@@ -279,9 +279,15 @@ __device__ __forceinline__ void store_obs_tile(T* __restrict__ dst, const T (&ob
 // ----------------------------------------------------------------------------------------
 // env-step kernel: GazeboRuntime.step (runtimes/gazebo_runtime.py:65-97) for every env
 // ----------------------------------------------------------------------------------------
+// LDS of one wave: during the physics iterations it holds the Minv*J^T rows of the contact
+// problem (3 rows x NQ values per body, one slot per lane); afterwards the same storage is the
+// observation tile of the coalesced [N][D] store.
+template <int NQ>
+constexpr int lds_words() { return kWave * (3 * NQ * NQ > OS2R_MAX_OBS ? 3 * NQ * NQ : OS2R_MAX_OBS); }
+
 template <typename T, int NQ, unsigned CMASK, bool DR, int AX0>
 __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
-  __shared__ T tile[kWave * OS2R_MAX_OBS];
+  __shared__ T tile[lds_words<NQ>()];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
@@ -322,7 +328,8 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   }
 
   for (int s = 0; s < A.substeps; ++s)  // runtimes/gazebo_runtime.py:70-77
-    substep<T, NQ, CMASK, DR, AX0>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters);
+    substep<T, NQ, CMASK, DR, AX0>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters, tile);
+  __syncthreads();
 
   bool bad = false;
 #pragma unroll

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Algorithmic flop count of one env-step of the stepper specification.
+
+Counts floating-point operations of the *algorithm* (an FMA = 2 flops, a reciprocal / division = 1,
+sin+cos = 40, tanh = 20), stage by stage, for a chain of nq joints with the sparsity the
+specification implies (axis-aligned joints, Jacobian of body b has b+1 columns).  The number of
+contact rows that do work is data dependent; it is measured by running the CPU oracle on a sample
+of the benchmark workload (mean number of bodies in contact per physics iteration).
+
+Writes profiles/flops.json, which bench.py uses for the `roofline_valu` object.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ROT_V, CROSS, DOT = 15, 9, 5          # 3x3 * vec, cross product, 3-dot
+
+
+def flops_substep(nq, ncand, contacts_mean, cols_mean, sweeps_n, sweeps_all, contact):
+    f = {}
+    f["sincos + joint rotations"] = nq * (40 + 12)
+    f["body velocities"] = (nq - 1) * (2 * ROT_V + CROSS + 3) + nq
+    per_joint = (25                      # rigid inertia about the frame origin
+                 + 15 + 2 * CROSS + 6 + 3 * CROSS      # bias force v x* I v
+                 + 27                                  # accumulate child inertia + bias
+                 + 4)                                  # U, D, 1/D, u
+    per_link = (42                       # Ia = IA - U U^T / D
+                + 8 + 2 * 15 + 2 * 15 + 12             # c, Ia c, U u / D
+                + 2 * 75 + 90                          # rotate A, M (symmetric) and H
+                + 3 * CROSS + 9 + 6 * CROSS + 12       # shift to the parent origin
+                + 2 * ROT_V + CROSS + 3)               # bias force to the parent
+    f["ABA inward pass"] = nq * per_joint + (nq - 1) * per_link
+    f["ABA outward pass"] = nq * (2 * ROT_V + 2 * CROSS + 2 * DOT + 8)
+    pairs = nq * (nq - 1) // 2
+    f["inverse mass matrix (unit-torque sweeps)"] = pairs * (2 * ROT_V + CROSS + 3 + 12) + pairs * (2 * ROT_V + CROSS) \
+        + (nq * (nq + 1) // 2) * (2 * DOT + 3)
+    if contact:
+        f["forward kinematics (world frames)"] = (nq - 1) * (45 + ROT_V + 3)
+        f["contact candidates"] = ncand * 10
+        per_contact = (ROT_V + 3 + 6) + cols_mean * CROSS + 3 * nq * 2 * cols_mean + 3 * 2 * cols_mean + 3
+        f["contact rows setup"] = contacts_mean * per_contact
+        row = 2 * cols_mean + 4 + 2 * nq
+    else:
+        contacts_mean, row = 0.0, 0.0
+    joint_rows = nq * (4 + 2 * nq)
+    f["PGS phase 1 (normal + joint friction rows)"] = sweeps_n * (contacts_mean * row + joint_rows)
+    f["PGS phase 2 (all rows)"] = sweeps_all * (3 * contacts_mean * row + joint_rows)
+    f["integration"] = 4 * nq
+    return f
+
+
+def measure_contacts(mode, dr, n=1024, steps=150, seed=42):
+    from helpers import make_config
+    from gym_os2r_amd import abi
+    from oracle import oracle_py as o
+    cfg, task, model = make_config(mode, "BalancingV1", True, num_envs=n, seed=seed, contact=True,
+                                   reset_mode=abi.RESET_RANDOM if dr else abi.RESET_FIXED, randomize_params=dr,
+                                   max_episode_steps=100000)
+    sim = o.OracleSim(cfg, threads=os.cpu_count() or 1)
+    tot, cols, cnt = 0.0, 0.0, 0
+    for t in range(steps):
+        sim.step(None)
+        if t % 10 == 9:
+            q, qd = sim.get_state()
+            for e in range(0, n, 8):
+                _, _, rw, ow = o.dynamics(cfg.model, q[:, e], qd[:, e], np.zeros(cfg.model.nq))
+                act, _, _ = o.contact_points(cfg.model, rw, ow, cfg.contact_margin)
+                tot += act.sum(); cols += sum(b + 1 for b in range(cfg.model.nq) if act[b]); cnt += 1
+    return tot / cnt, (cols / tot if tot else 0.0), cfg, model
+
+
+def main():
+    out = {}
+    for name, mode, contact, dr in (("C2", "fixed_hip", False, False), ("C3", "free_hip", True, False),
+                                    ("C4", "free_hip", True, True)):
+        if contact:
+            cm, colm, cfg, model = measure_contacts(mode, dr)
+        else:
+            from helpers import make_config
+            cfg, _, model = make_config(mode, "BalancingV1", True, num_envs=1, contact=False)
+            cm, colm = 0.0, 0.0
+        stages = flops_substep(model["nq"], model["ncand"], cm, colm, cfg.pgs_normal_iters, cfg.pgs_iters, contact)
+        sub = sum(stages.values())
+        epilogue = cfg.task.obs_dim * 8 + 5 * 20 + 30
+        total = cfg.substeps * sub + epilogue
+        for dt in ("f64", "f32"):
+            out[f"{name}_{dt}"] = {
+                "flops_per_env_step": round(total), "flops_per_physics_iteration": round(sub),
+                "mean_bodies_in_contact": round(cm, 3), "mean_jacobian_columns": round(colm, 3),
+                "stages_per_physics_iteration": {k: round(v, 1) for k, v in stages.items()},
+                "source": "tools/count_flops.py: analytic count of the specification; contact activity measured "
+                          "with the CPU oracle on 1024 envs x 150 random-action env-steps of the workload"}
+        print(name, "flops/env-step", round(total), "contacts", round(cm, 2))
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", "flops.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
