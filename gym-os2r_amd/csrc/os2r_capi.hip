@@ -16,6 +16,8 @@
 
 using namespace os2r;
 
+namespace os2r { int static_model_id(const Os2rModel& m); }
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -25,7 +27,7 @@ struct SimBase {
   std::string err;
   int nq = 0, D = 0;
   unsigned cmask = 0;
-  int ax0 = -1;  // axis of joint 0 when every later joint turns about x, else -1 (generic kernel)
+  int model_id = -1;  // matching constexpr model table, -1: run-time model kernels
   bool dr = false;
   size_t esz = 8;
   unsigned long long step_count = 0;
@@ -174,6 +176,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.pgs_normal_iters = s->cfg.pgs_normal_iters;
   a.auto_reset = s->cfg.auto_reset;
   a.dt = (T)s->cfg.dt; a.erp = (T)s->cfg.erp; a.max_erv = (T)s->cfg.max_erv; a.margin = (T)s->cfg.contact_margin;
+  a.gravity_z = (T)s->cfg.model.gravity_z;
   a.q = (T*)s->q; a.qd = (T*)s->qd; a.hist = (T*)s->hist;
   a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
@@ -195,7 +198,7 @@ template <typename T>
 int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* done, void* term, hipStream_t st) {
   StepArgs<T> a = make_args<T>(s);
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
-  if (Launcher<T>::step(s->nq, s->cmask, s->dr, s->ax0, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
+  if (Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
   HIP_TRY(s, hipGetLastError());
   s->step_count += 1;
   return OS2R_OK;
@@ -278,9 +281,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   // parameter arrays are read per lane only when something can make them differ per env:
   // the randomising reset mode, or a later os2r_set_params (which flips this on)
   s->dr = cfg->task.reset_mode == OS2R_RESET_RANDOM;
-  s->ax0 = cfg->model.axis[0];
-  for (int i = 1; i < cfg->model.nq; ++i)
-    if (cfg->model.axis[i] != 0) s->ax0 = -1;
+  s->model_id = static_model_id(cfg->model);
   s->cmask = 0;
   if (cfg->contact)
     for (int k = 0; k < cfg->model.ncand; ++k) s->cmask |= 1u << cfg->model.cand_body[k];

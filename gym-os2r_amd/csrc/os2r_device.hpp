@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "../../include/os2r.h"
+#include "os2r_models_gen.hpp"
 
 namespace os2r {
 
@@ -104,7 +105,7 @@ struct StepArgs {
   int pgs_iters;
   int pgs_normal_iters;
   int auto_reset;
-  T dt, erp, max_erv, margin;
+  T dt, erp, max_erv, margin, gravity_z;
   // state, SoA
   T* __restrict__ q;         // [nq][N]
   T* __restrict__ qd;        // [nq][N]
@@ -124,6 +125,55 @@ struct StepArgs {
   uint8_t* __restrict__ done;     // [N] or null
   T* __restrict__ term_obs;       // [N][D] or null
   const uint8_t* __restrict__ reset_mask;  // reset kernel only
+};
+
+// ----------------------------------------------------------------------------------------
+// Model access policies.  The device code reads robot constants only through these:
+//   RtModel<T,NQ>  any compiled serial chain, constants fetched with scalar loads at run time
+//   StModel<T,ID>  one of the reference's four URDF variants, constants are constexpr tables
+//                  (os2r_models_gen.hpp) folded into the instruction stream: no loads, no SGPR
+//                  pressure, and the exact zeros / ones of the fixed rotations disappear
+// ----------------------------------------------------------------------------------------
+template <typename T, int NQ_>
+struct RtModel {
+  static constexpr int NQ = NQ_;
+  static constexpr unsigned CMASK = (1u << NQ_) - 1u;
+  static constexpr bool kStatic = false;
+  ModelPtr<T> p;
+  __device__ __forceinline__ int axis(int i) const { return p->axis[i]; }
+  __device__ __forceinline__ T rfix(int i, int k) const { return p->rfix[i][k]; }
+  __device__ __forceinline__ T rpos(int i, int k) const { return p->rpos[i][k]; }
+  __device__ __forceinline__ T mass(int i) const { return p->mass[i]; }
+  __device__ __forceinline__ T com(int i, int k) const { return p->com[i][k]; }
+  __device__ __forceinline__ T icom(int i, int k) const { return p->icom[i][k]; }
+  __device__ __forceinline__ T damping(int i) const { return p->damping[i]; }
+  __device__ __forceinline__ T friction(int i) const { return p->friction[i]; }
+  __device__ __forceinline__ T mu(int i) const { return p->mu[i]; }
+  __device__ __forceinline__ int act_dof(int k) const { return p->act_dof[k]; }
+  __device__ __forceinline__ T max_torque(int k) const { return p->max_torque[k]; }
+  __device__ __forceinline__ int cand_begin(int b) const { return p->cand_begin[b]; }
+  __device__ __forceinline__ T cand(int k, int j) const { return p->cand_p[k][j]; }
+};
+
+template <typename T, int ID>
+struct StModel {
+  using Tb = gen::Tables<ID>;
+  static constexpr int NQ = Tb::nq;
+  static constexpr unsigned CMASK = Tb::cmask;
+  static constexpr bool kStatic = true;
+  __device__ __forceinline__ constexpr int axis(int i) const { return Tb::axis[i]; }
+  __device__ __forceinline__ constexpr T rfix(int i, int k) const { return (T)Tb::rfix[i][k]; }
+  __device__ __forceinline__ constexpr T rpos(int i, int k) const { return (T)Tb::rpos[i][k]; }
+  __device__ __forceinline__ constexpr T mass(int i) const { return (T)Tb::mass[i]; }
+  __device__ __forceinline__ constexpr T com(int i, int k) const { return (T)Tb::com[i][k]; }
+  __device__ __forceinline__ constexpr T icom(int i, int k) const { return (T)Tb::icom[i][k]; }
+  __device__ __forceinline__ constexpr T damping(int i) const { return (T)Tb::damping[i]; }
+  __device__ __forceinline__ constexpr T friction(int i) const { return (T)Tb::friction[i]; }
+  __device__ __forceinline__ constexpr T mu(int i) const { return (T)Tb::mu[i]; }
+  __device__ __forceinline__ constexpr int act_dof(int k) const { return Tb::act_dof[k]; }
+  __device__ __forceinline__ constexpr T max_torque(int k) const { return (T)Tb::max_torque[k]; }
+  __device__ __forceinline__ constexpr int cand_begin(int b) const { return Tb::cand_begin[b]; }
+  __device__ __forceinline__ constexpr T cand(int k, int j) const { return (T)Tb::cand_p[k][j]; }
 };
 
 // ----------------------------------------------------------------------------------------
@@ -194,6 +244,8 @@ template <typename T> __device__ __forceinline__ V3<T> rtmul(const T (&R)[9], V3
   return {R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z};
 }
 
+__device__ __forceinline__ double sqrt_t(double x) { return sqrt(x); }
+__device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
 __device__ __forceinline__ void sincos_t(double x, double& s, double& c) { sincos(x, &s, &c); }
 __device__ __forceinline__ void sincos_t(float x, float& s, float& c) { sincosf(x, &s, &c); }
 
@@ -240,39 +292,36 @@ template <typename T> __device__ __forceinline__ void rot_sym(const T (&R)[9], c
 // ----------------------------------------------------------------------------------------
 // per-lane physical parameters: nominal (uniform, SGPR) or randomised (per lane)
 // ----------------------------------------------------------------------------------------
-template <typename T, int NQ, bool DR>
+template <typename T, typename MD, bool DR>
 struct Params;
-template <typename T, int NQ>
-struct Params<T, NQ, false> {
-  ModelPtr<T> m;
-  __device__ __forceinline__ T mass(int i) const { return m->mass[i]; }
-  __device__ __forceinline__ T damping(int i) const { return m->damping[i]; }
-  __device__ __forceinline__ T friction(int i) const { return m->friction[i]; }
-  __device__ __forceinline__ T mu(int i) const { return m->mu[i]; }
-  __device__ __forceinline__ T gravity() const { return m->gravity_z; }
-};
-template <typename T, int NQ>
-struct Params<T, NQ, true> {
-  ModelPtr<T> m;
-  T ms[NQ], dm[NQ], fr[NQ], mu_[NQ], g;
-  __device__ __forceinline__ T mass(int i) const { return m->mass[i] * ms[i]; }
-  __device__ __forceinline__ T damping(int i) const { return dm[i]; }
-  __device__ __forceinline__ T friction(int i) const { return fr[i]; }
-  __device__ __forceinline__ T mu(int i) const { return mu_[i]; }
+template <typename T, typename MD>
+struct Params<T, MD, false> {
+  MD m;
+  T g;  // uniform gravity (a config value, not a model constant)
+  __device__ __forceinline__ T mass(int i) const { return m.mass(i); }
+  __device__ __forceinline__ T damping(int i) const { return m.damping(i); }
+  __device__ __forceinline__ T friction(int i) const { return m.friction(i); }
+  __device__ __forceinline__ T mu(int i) const { return m.mu(i); }
   __device__ __forceinline__ T gravity() const { return g; }
 };
-
-// ----------------------------------------------------------------------------------------
-// one physics iteration
-// ----------------------------------------------------------------------------------------
-// Joint axes: AX0 >= 0 fixes joint 0 to that axis and every later joint to x at compile time
-// (the reference's four URDF variants: yaw about z or none, then x-axis joints); AX0 < 0 reads
-// the axes from the model (any serial chain of x/y/z joints).
-template <int AX0, typename T>
-__device__ __forceinline__ int axis_of(ModelPtr<T> md, int i) {
-  if constexpr (AX0 >= 0) return i == 0 ? AX0 : 0;
-  else return md->axis[i];
-}
+// Randomised parameters are read from their HBM arrays at the point of use (one coalesced load
+// per value and physics iteration, L2-resident after the first) instead of being held in 42
+// registers for the whole kernel.
+template <typename T, typename MD>
+struct Params<T, MD, true> {
+  MD m;
+  const T* ms;  // [nq][N] each
+  const T* dm;
+  const T* fr;
+  const T* mu_;
+  long long N, e;
+  T g;
+  __device__ __forceinline__ T mass(int i) const { return m.mass(i) * ms[i * N + e]; }
+  __device__ __forceinline__ T damping(int i) const { return dm[i * N + e]; }
+  __device__ __forceinline__ T friction(int i) const { return fr[i * N + e]; }
+  __device__ __forceinline__ T mu(int i) const { return mu_[i * N + e]; }
+  __device__ __forceinline__ T gravity() const { return g; }
+};
 
 // Opaque copy: a fresh SSA value the optimiser cannot merge with earlier uses.  Used to
 // *re*-compute cheap quantities (a joint rotation is 12 FMAs) instead of holding them in
@@ -282,27 +331,31 @@ __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x));
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
 
 // R_i = Rfix_i * Rot(axis_i, q_i): child orientation in its parent, from (sin q_i, cos q_i)
-template <int AX0, typename T>
-__device__ __forceinline__ void joint_rotation(ModelPtr<T> md, int i, T s_, T c_, T (&R)[9]) {
+template <typename T, typename MD>
+__device__ __forceinline__ void joint_rotation(const MD& md, int i, T s_, T c_, T (&R)[9]) {
   const T s = opaque(s_), c = opaque(c_);
-  const OS2R_CONST T* F = md->rfix[i];
-  const int ax = axis_of<AX0>(md, i);
-  // columns ca, cb of F rotate into each other; column ax stays
+  const int ax = md.axis(i);
+  // columns ca, cb of Rfix rotate into each other; column ax stays
   const int ca = ax == 0 ? 1 : (ax == 1 ? 2 : 0);
   const int cb = ax == 0 ? 2 : (ax == 1 ? 0 : 1);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const T fa = F[3 * r + ca], fb = F[3 * r + cb];
-    R[3 * r + ax] = F[3 * r + ax];
+    const T fa = md.rfix(i, 3 * r + ca), fb = md.rfix(i, 3 * r + cb);
+    R[3 * r + ax] = md.rfix(i, 3 * r + ax);
     R[3 * r + ca] = c * fa + s * fb;
     R[3 * r + cb] = c * fb - s * fa;
   }
 }
 
-template <typename T, int NQ, unsigned CMASK, bool DR, int AX0>
-__device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>& par,
-                                        T (&q)[NQ], T (&qd)[NQ], T tau_hip, T tau_knee, T dt, T erp,
+template <typename T, typename MD, bool CONTACT, bool DR>
+__device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& par,
+                                        T (&q)[MD::NQ], T (&qd)[MD::NQ], T tau_hip, T tau_knee, T dt, T erp,
                                         T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds) {
+  constexpr int NQ = MD::NQ;
+  constexpr unsigned CMASK = CONTACT ? MD::CMASK : 0u;
+#ifdef OS2R_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef OS2R_MARK
   asm volatile("; SEC_1_sincos");
 #endif
@@ -311,140 +364,167 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
 #pragma unroll
   for (int i = 0; i < NQ; ++i) sincos_t(q[i], sn[i], cs[i]);
 
+  // Per-lane LDS slots (slot-major: lds[slot * 64 + lane], conflict free).  During the
+  // articulated-body passes they hold the per-joint quantities that must survive from one pass
+  // to the next (body velocities, U = I^A S, 1/D, u); afterwards the same storage holds the
+  // inverse mass matrix and the Minv*J^T rows of the contact problem.  Keeping these ~70 doubles
+  // out of the register file is what keeps the fp64 kernel free of scratch spills.
+  const int lane_ = threadIdx.x;
+  auto L = [&](int slot) -> T& { return lds[slot * kWave + lane_]; };
+  constexpr int kW = 0, kV = 3 * NQ, kUa = 6 * NQ, kUl = 9 * NQ, kDi = 12 * NQ, kU = 13 * NQ;  // 14*NQ slots
+  auto ldv = [&](int base, int i) { return mk(L(base + 3 * i), L(base + 3 * i + 1), L(base + 3 * i + 2)); };
+  auto stv = [&](int base, int i, V3<T> x) { L(base + 3 * i) = x.x; L(base + 3 * i + 1) = x.y; L(base + 3 * i + 2) = x.z; };
+
+#ifdef OS2R_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef OS2R_MARK
   asm volatile("; SEC_2a_vel");
 #endif
   // ---- 2a. body velocities (body coordinates), outward ----
-  V3<T> w[NQ], v[NQ];
+  {
+    V3<T> w = mk<T>(0, 0, 0), v = mk<T>(0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    if (i == 0) {
-      w[0] = mk<T>(0, 0, 0);
-      v[0] = mk<T>(0, 0, 0);
-    } else {
-      const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
-      T Ri[9];
-      joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
-      w[i] = rtmul(Ri, w[i - 1]);
-      v[i] = rtmul(Ri, v[i - 1] + cross(w[i - 1], r));
+    for (int i = 0; i < NQ; ++i) {
+      if (i > 0) {
+        const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
+        T Ri[9];
+        joint_rotation<T>(md, i, sn[i], cs[i], Ri);
+        const V3<T> wn = rtmul(Ri, w);
+        v = rtmul(Ri, v + cross(w, r));
+        w = wn;
+      }
+      add_comp(w, md.axis(i), qd[i]);
+      stv(kW, i, w);
+      stv(kV, i, v);
     }
-    add_comp(w[i], axis_of<AX0>(md, i), qd[i]);
   }
 
+#ifdef OS2R_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef OS2R_MARK
   asm volatile("; SEC_2b_inward");
 #endif
   // ---- 2b. articulated inertias and bias forces, inward ----
-  V3<T> Ua[NQ], Ul[NQ];  // U_i = I^A_i S_i  (angular, linear part)
-  T Dinv[NQ], u[NQ];
-  ArtInertia<T> acc;     // children's contribution, in the current body's frame
-  V3<T> pn, pf;          // children's bias force [moment; force]
+  {
+    ArtInertia<T> acc;     // children's contribution, in the current body's frame
+    V3<T> pn, pf;          // children's bias force [moment; force]
 #pragma unroll
-  for (int i = NQ - 1; i >= 0; --i) {
-    const int ax = axis_of<AX0>(md, i);
-    // rigid-body inertia of body i about its frame origin
-    const T m = par.mass(i);
-    const V3<T> cm = mk(md->com[i][0], md->com[i][1], md->com[i][2]);
-    const V3<T> h = m * cm;
-    ArtInertia<T> I;
-    I.A[0] = md->icom[i][0] + m * (cm.y * cm.y + cm.z * cm.z);
-    I.A[1] = md->icom[i][1] - m * cm.x * cm.y;
-    I.A[2] = md->icom[i][2] - m * cm.x * cm.z;
-    I.A[3] = md->icom[i][3] + m * (cm.x * cm.x + cm.z * cm.z);
-    I.A[4] = md->icom[i][4] - m * cm.y * cm.z;
-    I.A[5] = md->icom[i][5] + m * (cm.x * cm.x + cm.y * cm.y);
-    I.H[0] = 0; I.H[1] = -h.z; I.H[2] = h.y;
-    I.H[3] = h.z; I.H[4] = 0; I.H[5] = -h.x;
-    I.H[6] = -h.y; I.H[7] = h.x; I.H[8] = 0;
-    I.M[0] = m; I.M[1] = 0; I.M[2] = 0; I.M[3] = m; I.M[4] = 0; I.M[5] = m;
-    // rigid bias force v x* (I v)
-    const V3<T> nI = symmul(I.A, w[i]) + cross(h, v[i]);
-    const V3<T> fI = m * v[i] - cross(h, w[i]);
-    V3<T> pAn = cross(w[i], nI) + cross(v[i], fI);
-    V3<T> pAf = cross(w[i], fI);
-    if (i < NQ - 1) {
+    for (int i = NQ - 1; i >= 0; --i) {
+#ifdef OS2R_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      const int ax = md.axis(i);
+      const V3<T> w = ldv(kW, i), v = ldv(kV, i);
+      // rigid-body inertia of body i about its frame origin
+      const T m = par.mass(i);
+      const V3<T> cm = mk(md.com(i, 0), md.com(i, 1), md.com(i, 2));
+      const V3<T> h = m * cm;
+      ArtInertia<T> I;
+      I.A[0] = md.icom(i, 0) + m * (cm.y * cm.y + cm.z * cm.z);
+      I.A[1] = md.icom(i, 1) - m * cm.x * cm.y;
+      I.A[2] = md.icom(i, 2) - m * cm.x * cm.z;
+      I.A[3] = md.icom(i, 3) + m * (cm.x * cm.x + cm.z * cm.z);
+      I.A[4] = md.icom(i, 4) - m * cm.y * cm.z;
+      I.A[5] = md.icom(i, 5) + m * (cm.x * cm.x + cm.y * cm.y);
+      I.H[0] = 0; I.H[1] = -h.z; I.H[2] = h.y;
+      I.H[3] = h.z; I.H[4] = 0; I.H[5] = -h.x;
+      I.H[6] = -h.y; I.H[7] = h.x; I.H[8] = 0;
+      I.M[0] = m; I.M[1] = 0; I.M[2] = 0; I.M[3] = m; I.M[4] = 0; I.M[5] = m;
+      // rigid bias force v x* (I v)
+      const V3<T> nI = symmul(I.A, w) + cross(h, v);
+      const V3<T> fI = m * v - cross(h, w);
+      V3<T> pAn = cross(w, nI) + cross(v, fI);
+      V3<T> pAf = cross(w, fI);
+      if (i < NQ - 1) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { I.A[k] += acc.A[k]; I.M[k] += acc.M[k]; }
+        for (int k = 0; k < 6; ++k) { I.A[k] += acc.A[k]; I.M[k] += acc.M[k]; }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) I.H[k] += acc.H[k];
-      pAn = pAn + pn;
-      pAf = pAf + pf;
-    }
-    // U = I^A S : column `ax` of [[A],[H^T]]
-    const T Afull[9] = {I.A[0], I.A[1], I.A[2], I.A[1], I.A[3], I.A[4], I.A[2], I.A[4], I.A[5]};
-    Ua[i] = mk(Afull[ax], Afull[3 + ax], Afull[6 + ax]);
-    Ul[i] = mk(I.H[3 * ax], I.H[3 * ax + 1], I.H[3 * ax + 2]);
-    const T D = comp(Ua[i], ax) + dt * par.damping(i);
-    Dinv[i] = T(1) / D;
-    T tau = T(0);
-    if (i == md->act_dof[0]) tau = tau_hip;
-    if (i == md->act_dof[1]) tau = tau_knee;
-    u[i] = tau - par.damping(i) * qd[i] - comp(pAn, ax);
-    if (i > 0) {
-      // Ia = I^A - U U^T / D
-      const V3<T> ka = Dinv[i] * Ua[i], kl = Dinv[i] * Ul[i];
-      ArtInertia<T> Ia;
-      Ia.A[0] = I.A[0] - ka.x * Ua[i].x; Ia.A[1] = I.A[1] - ka.x * Ua[i].y; Ia.A[2] = I.A[2] - ka.x * Ua[i].z;
-      Ia.A[3] = I.A[3] - ka.y * Ua[i].y; Ia.A[4] = I.A[4] - ka.y * Ua[i].z; Ia.A[5] = I.A[5] - ka.z * Ua[i].z;
-      Ia.H[0] = I.H[0] - ka.x * Ul[i].x; Ia.H[1] = I.H[1] - ka.x * Ul[i].y; Ia.H[2] = I.H[2] - ka.x * Ul[i].z;
-      Ia.H[3] = I.H[3] - ka.y * Ul[i].x; Ia.H[4] = I.H[4] - ka.y * Ul[i].y; Ia.H[5] = I.H[5] - ka.y * Ul[i].z;
-      Ia.H[6] = I.H[6] - ka.z * Ul[i].x; Ia.H[7] = I.H[7] - ka.z * Ul[i].y; Ia.H[8] = I.H[8] - ka.z * Ul[i].z;
-      Ia.M[0] = I.M[0] - kl.x * Ul[i].x; Ia.M[1] = I.M[1] - kl.x * Ul[i].y; Ia.M[2] = I.M[2] - kl.x * Ul[i].z;
-      Ia.M[3] = I.M[3] - kl.y * Ul[i].y; Ia.M[4] = I.M[4] - kl.y * Ul[i].z; Ia.M[5] = I.M[5] - kl.z * Ul[i].z;
-      // velocity-product acceleration c = v x (S qd)
-      V3<T> sq = mk<T>(0, 0, 0);
-      add_comp(sq, ax, qd[i]);
-      const V3<T> ca = cross(w[i], sq), cl = cross(v[i], sq);
-      // pa = pA + Ia c + U u / D
-      const T Hfull_t0[3] = {Ia.H[0], Ia.H[3], Ia.H[6]};
-      const T Hfull_t1[3] = {Ia.H[1], Ia.H[4], Ia.H[7]};
-      const T Hfull_t2[3] = {Ia.H[2], Ia.H[5], Ia.H[8]};
-      const V3<T> Hc = mk(Ia.H[0] * cl.x + Ia.H[1] * cl.y + Ia.H[2] * cl.z, Ia.H[3] * cl.x + Ia.H[4] * cl.y + Ia.H[5] * cl.z,
-                          Ia.H[6] * cl.x + Ia.H[7] * cl.y + Ia.H[8] * cl.z);
-      const V3<T> Htc = mk(Hfull_t0[0] * ca.x + Hfull_t0[1] * ca.y + Hfull_t0[2] * ca.z,
-                           Hfull_t1[0] * ca.x + Hfull_t1[1] * ca.y + Hfull_t1[2] * ca.z,
-                           Hfull_t2[0] * ca.x + Hfull_t2[1] * ca.y + Hfull_t2[2] * ca.z);
-      const T ud = u[i] * Dinv[i];
-      const V3<T> pan = pAn + symmul(Ia.A, ca) + Hc + ud * Ua[i];
-      const V3<T> paf = pAf + Htc + symmul(Ia.M, cl) + ud * Ul[i];
-      // express in the parent frame: rotate by R_i, then shift by r_i
-      const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
-      T Ri[9];
-      joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
-      T Ar[6], Hr[9], Mr[6];
-      rot_sym(Ri, Ia.A, Ar);
-      rot_general(Ri, Ia.H, Hr);
-      rot_sym(Ri, Ia.M, Mr);
-      const T Mf[9] = {Mr[0], Mr[1], Mr[2], Mr[1], Mr[3], Mr[4], Mr[2], Mr[4], Mr[5]};
-      // H'' = Hr + r^ M  (column j: r x M[:,j])
-      T Hs[9];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const V3<T> col = cross(r, mk(Mf[j], Mf[3 + j], Mf[6 + j]));
-        Hs[j] = Hr[j] + col.x; Hs[3 + j] = Hr[3 + j] + col.y; Hs[6 + j] = Hr[6 + j] + col.z;
+        for (int k = 0; k < 9; ++k) I.H[k] += acc.H[k];
+        pAn = pAn + pn;
+        pAf = pAf + pf;
       }
-      // A''[i][j] = Ar[i][j] + (r x Hr_row_j)[i] + (r x Hs_row_i)[j]
-      V3<T> x0[3], x1[3];
+      // U = I^A S : column `ax` of [[A],[H^T]]
+      const T Afull[9] = {I.A[0], I.A[1], I.A[2], I.A[1], I.A[3], I.A[4], I.A[2], I.A[4], I.A[5]};
+      const V3<T> Ua = mk(Afull[ax], Afull[3 + ax], Afull[6 + ax]);
+      const V3<T> Ul = mk(I.H[3 * ax], I.H[3 * ax + 1], I.H[3 * ax + 2]);
+      const T damp = par.damping(i);
+      const T D = comp(Ua, ax) + dt * damp;
+      const T Dinv = T(1) / D;
+      T tau = T(0);
+      if (i == md.act_dof(0)) tau = tau_hip;
+      if (i == md.act_dof(1)) tau = tau_knee;
+      const T u = tau - damp * qd[i] - comp(pAn, ax);
+      stv(kUa, i, Ua);
+      stv(kUl, i, Ul);
+      L(kDi + i) = Dinv;
+      L(kU + i) = u;
+      if (i > 0) {
+        // Ia = I^A - U U^T / D
+        const V3<T> ka = Dinv * Ua, kl = Dinv * Ul;
+        ArtInertia<T> Ia;
+        Ia.A[0] = I.A[0] - ka.x * Ua.x; Ia.A[1] = I.A[1] - ka.x * Ua.y; Ia.A[2] = I.A[2] - ka.x * Ua.z;
+        Ia.A[3] = I.A[3] - ka.y * Ua.y; Ia.A[4] = I.A[4] - ka.y * Ua.z; Ia.A[5] = I.A[5] - ka.z * Ua.z;
+        Ia.H[0] = I.H[0] - ka.x * Ul.x; Ia.H[1] = I.H[1] - ka.x * Ul.y; Ia.H[2] = I.H[2] - ka.x * Ul.z;
+        Ia.H[3] = I.H[3] - ka.y * Ul.x; Ia.H[4] = I.H[4] - ka.y * Ul.y; Ia.H[5] = I.H[5] - ka.y * Ul.z;
+        Ia.H[6] = I.H[6] - ka.z * Ul.x; Ia.H[7] = I.H[7] - ka.z * Ul.y; Ia.H[8] = I.H[8] - ka.z * Ul.z;
+        Ia.M[0] = I.M[0] - kl.x * Ul.x; Ia.M[1] = I.M[1] - kl.x * Ul.y; Ia.M[2] = I.M[2] - kl.x * Ul.z;
+        Ia.M[3] = I.M[3] - kl.y * Ul.y; Ia.M[4] = I.M[4] - kl.y * Ul.z; Ia.M[5] = I.M[5] - kl.z * Ul.z;
+        // velocity-product acceleration c = v x (S qd)
+        V3<T> sq = mk<T>(0, 0, 0);
+        add_comp(sq, ax, qd[i]);
+        const V3<T> ca = cross(w, sq), cl = cross(v, sq);
+        // pa = pA + Ia c + U u / D
+        const V3<T> Hc = mk(Ia.H[0] * cl.x + Ia.H[1] * cl.y + Ia.H[2] * cl.z, Ia.H[3] * cl.x + Ia.H[4] * cl.y + Ia.H[5] * cl.z,
+                            Ia.H[6] * cl.x + Ia.H[7] * cl.y + Ia.H[8] * cl.z);
+        const V3<T> Htc = mk(Ia.H[0] * ca.x + Ia.H[3] * ca.y + Ia.H[6] * ca.z, Ia.H[1] * ca.x + Ia.H[4] * ca.y + Ia.H[7] * ca.z,
+                             Ia.H[2] * ca.x + Ia.H[5] * ca.y + Ia.H[8] * ca.z);
+        const T ud = u * Dinv;
+        const V3<T> pan = pAn + symmul(Ia.A, ca) + Hc + ud * Ua;
+        const V3<T> paf = pAf + Htc + symmul(Ia.M, cl) + ud * Ul;
+        // express in the parent frame: rotate by R_i, then shift by r_i
+        const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
+        T Ri[9];
+        joint_rotation<T>(md, i, sn[i], cs[i], Ri);
+        T Ar[6], Hr[9], Mr[6];
+        rot_sym(Ri, Ia.A, Ar);
+        rot_general(Ri, Ia.H, Hr);
+        rot_sym(Ri, Ia.M, Mr);
+        const T Mf[9] = {Mr[0], Mr[1], Mr[2], Mr[1], Mr[3], Mr[4], Mr[2], Mr[4], Mr[5]};
+        // H'' = Hr + r^ M  (column j: r x M[:,j])
+        T Hs[9];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        x0[k] = cross(r, mk(Hr[3 * k], Hr[3 * k + 1], Hr[3 * k + 2]));
-        x1[k] = cross(r, mk(Hs[3 * k], Hs[3 * k + 1], Hs[3 * k + 2]));
+        for (int j = 0; j < 3; ++j) {
+          const V3<T> col = cross(r, mk(Mf[j], Mf[3 + j], Mf[6 + j]));
+          Hs[j] = Hr[j] + col.x; Hs[3 + j] = Hr[3 + j] + col.y; Hs[6 + j] = Hr[6 + j] + col.z;
+        }
+        // A''[i][j] = Ar[i][j] + (r x Hr_row_j)[i] + (r x Hs_row_i)[j]
+        V3<T> x0[3], x1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          x0[k] = cross(r, mk(Hr[3 * k], Hr[3 * k + 1], Hr[3 * k + 2]));
+          x1[k] = cross(r, mk(Hs[3 * k], Hs[3 * k + 1], Hs[3 * k + 2]));
+        }
+        acc.A[0] = Ar[0] + x0[0].x + x1[0].x;
+        acc.A[1] = Ar[1] + x0[1].x + x1[0].y;
+        acc.A[2] = Ar[2] + x0[2].x + x1[0].z;
+        acc.A[3] = Ar[3] + x0[1].y + x1[1].y;
+        acc.A[4] = Ar[4] + x0[2].y + x1[1].z;
+        acc.A[5] = Ar[5] + x0[2].z + x1[2].z;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc.H[k] = Hs[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc.M[k] = Mr[k];
+        pf = rmul(Ri, paf);
+        pn = rmul(Ri, pan) + cross(r, pf);
       }
-      acc.A[0] = Ar[0] + x0[0].x + x1[0].x;
-      acc.A[1] = Ar[1] + x0[1].x + x1[0].y;
-      acc.A[2] = Ar[2] + x0[2].x + x1[0].z;
-      acc.A[3] = Ar[3] + x0[1].y + x1[1].y;
-      acc.A[4] = Ar[4] + x0[2].y + x1[1].z;
-      acc.A[5] = Ar[5] + x0[2].z + x1[2].z;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) acc.H[k] = Hs[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc.M[k] = Mr[k];
-      pf = rmul(Ri, paf);
-      pn = rmul(Ri, pan) + cross(r, pf);
     }
   }
 
+#ifdef OS2R_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef OS2R_MARK
   asm volatile("; SEC_2c_outward");
 #endif
@@ -454,22 +534,25 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, -par.gravity());
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int ax = axis_of<AX0>(md, i);
-      const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+      const int ax = md.axis(i);
+      const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
       V3<T> sq = mk<T>(0, 0, 0);
       add_comp(sq, ax, qd[i]);
       T Ri[9];
-      joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
+      joint_rotation<T>(md, i, sn[i], cs[i], Ri);
       const V3<T> pa_ = rtmul(Ri, aa);
       const V3<T> pl_ = rtmul(Ri, al + cross(aa, r));
-      aa = pa_ + cross(w[i], sq);
-      al = pl_ + cross(v[i], sq);
-      const T qdd = (u[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
+      aa = pa_ + cross(ldv(kW, i), sq);
+      al = pl_ + cross(ldv(kV, i), sq);
+      const T qdd = (L(kU + i) - dot(ldv(kUa, i), aa) - dot(ldv(kUl, i), al)) * L(kDi + i);
       add_comp(aa, ax, qdd);
       vs[i] = qd[i] + dt * qdd;
     }
   }
 
+#ifdef OS2R_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef OS2R_MARK
   asm volatile("; SEC_3_minv");
 #endif
@@ -479,50 +562,90 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
   for (int k = 0; k < NQ; ++k) {
     T uk[NQ];
     uk[k] = T(1);
-    V3<T> pn_ = Dinv[k] * Ua[k], pf_ = Dinv[k] * Ul[k];
+    const T dk = L(kDi + k);
+    V3<T> pn_ = dk * ldv(kUa, k), pf_ = dk * ldv(kUl, k);
 #pragma unroll
     for (int i = k - 1; i >= 0; --i) {
       // bias force of body i+1 expressed in body i
-      const V3<T> r = mk(md->rpos[i + 1][0], md->rpos[i + 1][1], md->rpos[i + 1][2]);
+      const V3<T> r = mk(md.rpos(i + 1, 0), md.rpos(i + 1, 1), md.rpos(i + 1, 2));
       T Ri[9];
-      joint_rotation<AX0>(md, i + 1, sn[i + 1], cs[i + 1], Ri);
+      joint_rotation<T>(md, i + 1, sn[i + 1], cs[i + 1], Ri);
       const V3<T> f = rmul(Ri, pf_);
       const V3<T> n = rmul(Ri, pn_) + cross(r, f);
-      uk[i] = -comp(n, axis_of<AX0>(md, i));
-      const T s = uk[i] * Dinv[i];
-      pn_ = n + s * Ua[i];
-      pf_ = f + s * Ul[i];
+      uk[i] = -comp(n, md.axis(i));
+      const T s = uk[i] * L(kDi + i);
+      pn_ = n + s * ldv(kUa, i);
+      pf_ = f + s * ldv(kUl, i);
     }
     V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, 0);
 #pragma unroll
     for (int i = 0; i <= k; ++i) {
       if (i > 0) {
-        const V3<T> r = mk(md->rpos[i][0], md->rpos[i][1], md->rpos[i][2]);
+        const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
         T Ri[9];
-        joint_rotation<AX0>(md, i, sn[i], cs[i], Ri);
+        joint_rotation<T>(md, i, sn[i], cs[i], Ri);
         const V3<T> na = rtmul(Ri, aa);
         al = rtmul(Ri, al + cross(aa, r));
         aa = na;
       }
-      const T x = (uk[i] - dot(Ua[i], aa) - dot(Ul[i], al)) * Dinv[i];
+      const T x = (uk[i] - dot(ldv(kUa, i), aa) - dot(ldv(kUl, i), al)) * L(kDi + i);
       Mi[i][k] = x;
       Mi[k][i] = x;
-      add_comp(aa, axis_of<AX0>(md, i), x);
+      add_comp(aa, md.axis(i), x);
     }
   }
+
+  // ---- 4. whitening: Minv = Lc Lc^T (Cholesky, lower), y = Lc^-1 v ----
+  // The constraint rows are solved in the coordinates y: for a row with Jacobian J_r,
+  // J_r v = G_r y and the velocity response Minv J_r^T dl = Lc (G_r^T dl) with G_r = J_r Lc, so one
+  // vector per row serves both the residual and the update, and because Lc is lower triangular
+  // G_r of a contact on body b (and of the friction row of joint b) has only b+1 non-zeros.
+  // This halves the per-row storage and work of the sweep compared with keeping J_r and
+  // Minv J_r^T; the rows live in the wave's LDS (the articulated-body slots are dead by now).
+  constexpr int NB = NQ;
+  constexpr int kLc = 0;                       // Lc[i][k], k <= i, at kLc + i*(i+1)/2 + k
+  constexpr int kG = NQ * (NQ + 1) / 2;        // rows of body b at kG + 3*b*(b+1)/2 + row*(b+1) + k
+  auto Lcs = [&](int i, int k) -> T& { return L(kLc + i * (i + 1) / 2 + k); };
+  auto Gs = [&](int b, int row, int k) -> T& { return L(kG + 3 * b * (b + 1) / 2 + row * (b + 1) + k); };
+  T y[NQ];
+  T idj[NQ];  // reciprocal of Minv[j][j] = |row j of Lc|^2 (joint friction rows)
+  {
+    T Lc[NQ][NQ], Ldi[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      T sdiag = Mi[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sdiag -= Lc[j][k] * Lc[j][k];
+      Lc[j][j] = sqrt_t(sdiag);
+      Ldi[j] = T(1) / Lc[j][j];
+      Lcs(j, j) = Lc[j][j];
+#pragma unroll
+      for (int i = j + 1; i < NQ; ++i) {
+        T sod = Mi[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sod -= Lc[i][k] * Lc[j][k];
+        Lc[i][j] = sod * Ldi[j];
+        Lcs(i, j) = Lc[i][j];
+      }
+      idj[j] = Mi[j][j] > T(0) ? T(1) / Mi[j][j] : T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      T acc_ = vs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) acc_ -= Lc[i][k] * y[k];
+      y[i] = acc_ * Ldi[i];
+    }
+  }
+  T y0[NQ];  // only the change of y is mapped back, so an idle solve leaves v bit-identical
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) y0[i] = y[i];
 
 #ifdef OS2R_MARK
   asm volatile("; SEC_5_contacts");
 #endif
   // ---- 5. ground contact candidates -> one point contact per body ----
-  // rows live in registers with static indexing; bodies without candidates compile out (CMASK)
-  constexpr int NB = NQ;
-  T Jn[NB][NQ], Jx[NB][NQ], Jy[NB][NQ];  // Jacobian rows: normal z, tangents x, y
-  // Minv * J^T of every row lives in LDS, one 8/4-byte slot per lane per value (slot-major, so a
-  // wave's access is 64 consecutive words: conflict free): Tl(b, row, j)
-  const int lane_ = threadIdx.x;
-  auto Tl = [&](int b, int row, int j) -> T& { return lds[((b * 3 + row) * NQ + j) * kWave + lane_]; };
-  T dn[NB], dx[NB], dy[NB], erv[NB];  // dn/dx/dy: reciprocal of J Minv J^T per row (0: row off)
+  T dn[NB], dx[NB], dy[NB], erv[NB];  // dn/dx/dy: reciprocal of J Minv J^T = |G_r|^2 per row (0: row off)
   bool act[NB];
   bool wave_act[NB];
 #pragma unroll
@@ -532,9 +655,9 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     V3<T> aw[NQ], jo[NQ];  // world joint axes and joint origins
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const V3<T> r = mk(md->rpos[b][0], md->rpos[b][1], md->rpos[b][2]);
+      const V3<T> r = mk(md.rpos(b, 0), md.rpos(b, 1), md.rpos(b, 2));
       T Rb[9];
-      joint_rotation<AX0>(md, b, sn[b], cs[b], Rb);
+      joint_rotation<T>(md, b, sn[b], cs[b], Rb);
       if (b == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rw[k] = Rb[k];
@@ -550,14 +673,15 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rw[k] = n[k];
       }
-      const int ax = axis_of<AX0>(md, b);
+      const int ax = md.axis(b);
       aw[b] = mk(Rw[ax], Rw[3 + ax], Rw[6 + ax]);
       jo[b] = mk(ow[0], ow[1], ow[2]);
       if (!((CMASK >> b) & 1u)) continue;
-      const int k0 = md->cand_begin[b], k1 = md->cand_begin[b + 1];
+      const int k0 = md.cand_begin(b), k1 = md.cand_begin(b + 1);
       T W = 0, sx = 0, sy = 0, sz = 0;
+#pragma unroll 4
       for (int k = k0; k < k1; ++k) {
-        const T px = md->cand_p[k][0], py = md->cand_p[k][1], pz = md->cand_p[k][2];
+        const T px = md.cand(k, 0), py = md.cand(k, 1), pz = md.cand(k, 2);
         const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
         const T wgt = z < margin ? margin - z : T(0);
         W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
@@ -573,23 +697,26 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
         const T gap = pw.z;
         const T e = erp * (-gap) / dt;
         erv[b] = gap >= T(0) ? -gap / dt : (e > max_erv ? max_erv : e);
+        T Jn[NQ], Jx[NQ], Jy[NQ];  // Jacobian rows of the contact point: normal z, tangents x, y
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
           if (j <= b) {
             const V3<T> c = cross(aw[j], pw - jo[j]);
-            Jx[b][j] = c.x; Jy[b][j] = c.y; Jn[b][j] = c.z;
-          } else {
-            Jx[b][j] = 0; Jy[b][j] = 0; Jn[b][j] = 0;
+            Jx[j] = c.x; Jy[j] = c.y; Jn[j] = c.z;
           }
         }
+        // G = J Lc (b+1 non-zeros), d = |G|^2
         T sdn = 0, sdx = 0, sdy = 0;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-          T tn = 0, tx = 0, ty = 0;
+        for (int k = 0; k < NQ; ++k) {
+          if (k <= b) {
+            T gn = 0, gx = 0, gy = 0;
 #pragma unroll
-          for (int j = 0; j <= b; ++j) { tn += Mi[i][j] * Jn[b][j]; tx += Mi[i][j] * Jx[b][j]; ty += Mi[i][j] * Jy[b][j]; }
-          Tl(b, 0, i) = tn; Tl(b, 1, i) = tx; Tl(b, 2, i) = ty;
-          if (i <= b) { sdn += Jn[b][i] * tn; sdx += Jx[b][i] * tx; sdy += Jy[b][i] * ty; }
+            for (int j = k; j < NQ; ++j)
+              if (j <= b) { const T l = Lcs(j, k); gn += Jn[j] * l; gx += Jx[j] * l; gy += Jy[j] * l; }
+            Gs(b, 0, k) = gn; Gs(b, 1, k) = gx; Gs(b, 2, k) = gy;
+            sdn += gn * gn; sdx += gx * gx; sdy += gy * gy;
+          }
         }
         // reciprocals once per iteration of the physics, not once per row update
         dn[b] = sdn > T(0) ? T(1) / sdn : T(0); dx[b] = sdx > T(0) ? T(1) / sdx : T(0); dy[b] = sdy > T(0) ? T(1) / sdy : T(0);
@@ -600,17 +727,17 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
 #ifdef OS2R_MARK
   asm volatile("; SEC_6_pgs");
 #endif
-  // ---- 6. projected Gauss-Seidel on the velocities ----
+  // ---- 6. projected Gauss-Seidel on the (whitened) velocities ----
   T ln[NB], lx[NB], ly[NB], lf[NQ];
 #pragma unroll
   for (int b = 0; b < NB; ++b) { ln[b] = 0; lx[b] = 0; ly[b] = 0; }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) lf[j] = 0;
-  T fb[NQ], imjj[NQ];  // joint friction impulse bound, 1 / Minv[j][j] (0: row off)
+  T fb[NQ];  // joint friction impulse bound
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
     fb[j] = par.friction(j) * dt;
-    imjj[j] = (fb[j] > T(0) && Mi[j][j] > T(0)) ? T(1) / Mi[j][j] : T(0);
+    idj[j] = fb[j] > T(0) ? idj[j] : T(0);
   }
 
   // Phase 1 (pgs_normal_iters sweeps): normal rows and joint-friction rows only; its normal
@@ -619,53 +746,49 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
   // unique velocity solution.  pgs_normal_iters == 0 selects the coupled pyramid (bounds follow
   // the current normal impulse inside the sweep), which is ill-posed for a slender leg sliding
   // at mu ~ 1 (Painleve) and is kept for experiments only.
-  auto normal_row = [&](int b) {
-    T res = -erv[b];
+  auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi) {
+    T g[NQ];
+    T res = -target;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j)
-      if (j <= b) res += Jn[b][j] * vs[j];
-    T lam = ln[b] - res * dn[b];
-    lam = lam < T(0) ? T(0) : lam;
-    lam = act[b] ? lam : ln[b];
-    const T dl = lam - ln[b];
-    ln[b] = lam;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) vs[j] += Tl(b, 0, j) * dl;
-  };
-  auto tangent_row = [&](int b, const T (&J)[NB][NQ], int row, T d, T& l, T lim) {
-    T res = 0;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j)
-      if (j <= b) res += J[b][j] * vs[j];
-    T lam = l - res * d;
-    lam = lam < -lim ? -lim : lam;
-    lam = lam > lim ? lim : lam;
-    lam = (act[b] && d > T(0)) ? lam : l;
+    for (int k = 0; k < NQ; ++k)
+      if (k <= b) { g[k] = Gs(b, row, k); res += g[k] * y[k]; }
+    T lam = l - res * rd;
+    lam = lam < lo ? lo : lam;
+    lam = lam > hi ? hi : lam;
+    lam = (act[b] && rd > T(0)) ? lam : l;
     const T dl = lam - l;
     l = lam;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) vs[j] += Tl(b, row, j) * dl;
+    for (int k = 0; k < NQ; ++k)
+      if (k <= b) y[k] += g[k] * dl;
   };
   auto joint_rows = [&]() {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-      // joint Coulomb friction row: J = e_j, T = Minv[:, j], d = Minv[j][j]
-      T lam = lf[j] - vs[j] * imjj[j];
+      // joint Coulomb friction row: J = e_j, G = row j of Lc, d = Minv[j][j]
+      T g[NQ];
+      T res = 0;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k)
+        if (k <= j) { g[k] = Lcs(j, k); res += g[k] * y[k]; }
+      T lam = lf[j] - res * idj[j];
       lam = lam < -fb[j] ? -fb[j] : lam;
       lam = lam > fb[j] ? fb[j] : lam;
-      lam = imjj[j] > T(0) ? lam : lf[j];
+      lam = idj[j] > T(0) ? lam : lf[j];
       const T dl = lam - lf[j];
       lf[j] = lam;
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) vs[i] += Mi[i][j] * dl;
+      for (int k = 0; k < NQ; ++k)
+        if (k <= j) y[k] += g[k] * dl;
     }
   };
+  const T kInf = T(1e300) * T(1e300);
   const bool fixed_box = pgs_normal_iters > 0;
   for (int it = 0; it < pgs_normal_iters; ++it) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
-      if (wave_act[b]) normal_row(b);
+      if (wave_act[b]) contact_row(b, 0, erv[b], dn[b], ln[b], T(0), kInf);
     }
     joint_rows();
   }
@@ -677,14 +800,26 @@ __device__ __forceinline__ void substep(ModelPtr<T> md, const Params<T, NQ, DR>&
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (!wave_act[b]) continue;
-      normal_row(b);
+      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), kInf);
       const T lim = fixed_box ? limfix[b] : par.mu(b) * ln[b];
-      tangent_row(b, Jx, 1, dx[b], lx[b], lim);
-      tangent_row(b, Jy, 2, dy[b], ly[b], lim);
+      contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim);
+      contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim);
     }
     joint_rows();
   }
+  // back to joint velocities: v += Lc (y - y0)
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    T acc_ = 0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+      if (k <= i) acc_ += Lcs(i, k) * (y[k] - y0[k]);
+    vs[i] += acc_;
+  }
 
+#ifdef OS2R_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifdef OS2R_MARK
   asm volatile("; SEC_7_integrate");
 #endif

@@ -14,8 +14,6 @@ __device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
 __device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
 __device__ __forceinline__ double fmod_t(double a, double b) { return fmod(a, b); }
 __device__ __forceinline__ float fmod_t(float a, float b) { return fmodf(a, b); }
-__device__ __forceinline__ double sqrt_t(double x) { return sqrt(x); }
-__device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
 __device__ __forceinline__ double fabs_t(double x) { return fabs(x); }
 __device__ __forceinline__ float fabs_t(float x) { return fabsf(x); }
 __device__ __forceinline__ double atanh_t(double x) { return atanh(x); }
@@ -162,10 +160,18 @@ __device__ __forceinline__ void leg_joint_angles(const double (&def6)[6], double
 
 // Reset of one environment: randomizers/monopod_no_rand.py:59-98 (fixed) and
 // randomizers/monopod.py:89-128,182-215 (randomised pose + parameter resampling).
-template <typename T, int NQ, bool DR>
-__device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uint32_t epi, T (&q)[NQ], T (&qd)[NQ],
-                                          Params<T, NQ, DR>& par, uint8_t& pose) {
+// freshly sampled per-env parameters of a reset (written back by store_params)
+template <typename T, int NQ>
+struct ParamVals {
+  T ms[NQ], dm[NQ], fr[NQ], mu_[NQ];
+  bool fresh = false;
+};
+
+template <typename T, typename MD, bool DR>
+__device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uint32_t epi, T (&q)[MD::NQ], T (&qd)[MD::NQ],
+                                          ParamVals<T, MD::NQ>& par, uint8_t& pose) {
 #pragma clang fp contract(off)
+  constexpr int NQ = MD::NQ;
   const TaskPtr<T> ts = as_const(A.task);
   const uint32_t genv = (uint32_t)(A.env_offset + e);
   double u0, u1;
@@ -230,33 +236,32 @@ __device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uin
         par.dm[i] = (T)(ts->nominal_damping[i] * (ts->dr_damping_lo + (ts->dr_damping_hi - ts->dr_damping_lo) * b0));
         par.mu_[i] = (T)(ts->dr_mu_base * (ts->dr_mu_lo + (ts->dr_mu_hi - ts->dr_mu_lo) * b1));
       }
+      par.fresh = true;
     }
   }
 }
 
-template <typename T, int NQ, bool DR>
-__device__ __forceinline__ void load_params(const StepArgs<T>& A, long long e, Params<T, NQ, DR>& par) {
-  par.m = as_const(A.model);
+template <typename T, typename MD, bool DR>
+__device__ __forceinline__ void bind_params(const StepArgs<T>& A, long long e, const MD& md, Params<T, MD, DR>& par) {
+  par.m = md;
+  if constexpr (!DR) par.g = A.gravity_z;
   if constexpr (DR) {
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      par.ms[i] = A.mass_scale[i * A.N + e];
-      par.dm[i] = A.damping[i * A.N + e];
-      par.fr[i] = A.friction[i * A.N + e];
-      par.mu_[i] = A.mu[i * A.N + e];
-    }
-    par.g = A.gravity[e];
+    // opaque base pointers: the loads below them cannot be hoisted out of the caller's loop
+    const T* a = A.mass_scale; const T* b = A.damping; const T* c = A.friction; const T* d = A.mu;
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+    par.ms = a; par.dm = b; par.fr = c; par.mu_ = d;
+    par.N = A.N; par.e = e;
   }
 }
-template <typename T, int NQ, bool DR>
-__device__ __forceinline__ void store_params(const StepArgs<T>& A, long long e, const Params<T, NQ, DR>& par) {
-  if constexpr (DR) {
+template <typename T, int NQ>
+__device__ __forceinline__ void store_params(const StepArgs<T>& A, long long e, const ParamVals<T, NQ>& pv) {
+  if (pv.fresh) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      A.mass_scale[i * A.N + e] = par.ms[i];
-      A.damping[i * A.N + e] = par.dm[i];
-      A.friction[i * A.N + e] = par.fr[i];
-      A.mu[i * A.N + e] = par.mu_[i];
+      A.mass_scale[i * A.N + e] = pv.ms[i];
+      A.damping[i * A.N + e] = pv.dm[i];
+      A.friction[i * A.N + e] = pv.fr[i];
+      A.mu[i * A.N + e] = pv.mu_[i];
     }
   }
 }
@@ -283,16 +288,28 @@ __device__ __forceinline__ void store_obs_tile(T* __restrict__ dst, const T (&ob
 // problem (3 rows x NQ values per body, one slot per lane); afterwards the same storage is the
 // observation tile of the coalesced [N][D] store.
 template <int NQ>
-constexpr int lds_words() { return kWave * (3 * NQ * NQ > OS2R_MAX_OBS ? 3 * NQ * NQ : OS2R_MAX_OBS); }
+constexpr int lds_words() {
+  // contact rows G (3 rows x (b+1) per body) + Cholesky factor of Minv / per-joint ABA data
+  constexpr int rows = 3 * NQ * (NQ + 1) / 2 + NQ * (NQ + 1) / 2, aba = 14 * NQ;
+  constexpr int m = rows > aba ? rows : aba;
+  return kWave * (m > OS2R_MAX_OBS ? m : OS2R_MAX_OBS);
+}
 
-template <typename T, int NQ, unsigned CMASK, bool DR, int AX0>
+template <typename T, typename MD>
+__device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
+  if constexpr (MD::kStatic) return MD{};
+  else return MD{as_const(A.model)};
+}
+
+template <typename T, typename MD, bool CONTACT, bool DR>
 __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
+  constexpr int NQ = MD::NQ;
   __shared__ T tile[lds_words<NQ>()];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
   const long long e = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
-  const ModelPtr<T> md = as_const(A.model);
+  const MD md = make_model<T, MD>(A);
   const TaskPtr<T> ts = as_const(A.task);
 
   T q[NQ], qd[NQ];
@@ -301,8 +318,9 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
     q[i] = A.q[i * A.N + e];
     qd[i] = A.qd[i * A.N + e];
   }
-  Params<T, NQ, DR> par;
-  load_params<T, NQ, DR>(A, e, par);
+  Params<T, MD, DR> par;
+  bind_params<T, MD, DR>(A, e, md, par);
+  if constexpr (DR) par.g = A.gravity[e];
 
   // action: caller-provided or drawn from the counter RNG (stream 1, counter = step count)
   T ax, ay;
@@ -321,14 +339,16 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   T tau_hip, tau_knee, asx, asy;
   {
 #pragma clang fp contract(off)
-    tau_hip = md->max_torque[0] * ax;    // tasks/monopod.py:223
-    tau_knee = md->max_torque[1] * ay;
-    asx = tau_hip / md->max_torque[0];   // what action_history stores (:233-235)
-    asy = tau_knee / md->max_torque[1];
+    tau_hip = md.max_torque(0) * ax;    // tasks/monopod.py:223
+    tau_knee = md.max_torque(1) * ay;
+    asx = tau_hip / md.max_torque(0);   // what action_history stores (:233-235)
+    asy = tau_knee / md.max_torque(1);
   }
 
-  for (int s = 0; s < A.substeps; ++s)  // runtimes/gazebo_runtime.py:70-77
-    substep<T, NQ, CMASK, DR, AX0>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters, tile);
+  for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
+    if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
+    substep<T, MD, CONTACT, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters, tile);
+  }
   __syncthreads();
 
   bool bad = false;
@@ -350,9 +370,10 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   uint32_t epi = A.episode[e];
   uint8_t pose = A.pose[e];
   const bool do_reset = flag != 0 && A.auto_reset != 0;
+  ParamVals<T, NQ> pv;
   if (__ballot(do_reset) != 0ull) {
     if (do_reset) {
-      reset_env<T, NQ, DR>(A, e, epi, q, qd, par, pose);
+      reset_env<T, MD, DR>(A, e, epi, q, qd, pv, pose);
       epi += 1;
       steps = 0;
       bool dn2;
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
     if (do_reset) {
       A.episode[e] = epi;
       A.pose[e] = pose;
-      store_params<T, NQ, DR>(A, e, par);
+      store_params<T, NQ>(A, e, pv);
     }
     if (A.reward) A.reward[e] = rew;
     if (A.done) A.done[e] = flag;
@@ -399,13 +420,13 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const StepArgs<T> A) {
     q[i] = A.q[i * A.N + e];
     qd[i] = A.qd[i * A.N + e];
   }
-  Params<T, NQ, DR> par;
-  load_params<T, NQ, DR>(A, e, par);
+  using MD = RtModel<T, NQ>;
+  ParamVals<T, NQ> pv;
   const bool doit = A.reset_mask ? A.reset_mask[e] != 0 : true;
   uint32_t epi = A.episode[e];
   uint8_t pose = A.pose[e];
   if (doit) {
-    reset_env<T, NQ, DR>(A, e, epi, q, qd, par, pose);
+    reset_env<T, MD, DR>(A, e, epi, q, qd, pv, pose);
     epi += 1;
   }
   const T h1x = A.hist[2 * A.N + e], h1y = A.hist[3 * A.N + e];
@@ -422,7 +443,7 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const StepArgs<T> A) {
     A.episode[e] = epi;
     A.pose[e] = pose;
     A.steps[e] = 0;
-    store_params<T, NQ, DR>(A, e, par);
+    store_params<T, NQ>(A, e, pv);
   }
 }
 
@@ -446,7 +467,8 @@ __global__ void fill_kernel(T* __restrict__ dst, long long n, T value) {
 // launch tables (defined in the per-dtype instantiation units)
 template <typename T>
 struct Launcher {
-  static int step(int nq, unsigned cmask, bool dr, int ax0, const StepArgs<T>& args, hipStream_t stream);
+  // model_id: index of the matching constexpr table (os2r_models_gen.hpp) or -1 for the run-time model
+  static int step(int nq, int model_id, bool contact, bool dr, const StepArgs<T>& args, hipStream_t stream);
   static int reset(int nq, bool dr, const StepArgs<T>& args, hipStream_t stream);
   static void gravity(T* g, long long N, long long off, unsigned long long seed, double mean, double std_, hipStream_t s);
   static void fill(T* dst, long long n, T value, hipStream_t s);
