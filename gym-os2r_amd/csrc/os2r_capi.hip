@@ -43,6 +43,7 @@ struct SimBase {
   void *b_obs = nullptr, *b_rew = nullptr;
   uint8_t* b_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* debug = nullptr;  // diagnostic stamp builds only
 };
 
 }  // namespace
@@ -181,6 +182,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
   a.steps = s->steps; a.episode = s->episode; a.pose = s->pose;
+  a.debug = s->debug;
   return a;
 }
 
@@ -430,6 +432,15 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) 
   HIP_TRY(sim, hipEventElapsedTime(elapsed_ms, sim->ev0, sim->ev1));
   return OS2R_OK;
 }
+
+#ifdef OS2R_STAMPS
+// diagnostic builds only (libos2r_stamps.so): per-wave phase stamps, 8 x uint64 per workgroup
+int os2r_debug_set_stamp_buffer(Os2rSim* sim, unsigned long long* buf_dev) {
+  if (!sim) return OS2R_ERR_INVALID;
+  sim->debug = buf_dev;
+  return OS2R_OK;
+}
+#endif
 
 const char* os2r_last_error(Os2rSim* sim) { return sim ? sim->err.c_str() : g_create_error.c_str(); }
 

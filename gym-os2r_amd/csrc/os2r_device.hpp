@@ -125,6 +125,7 @@ struct StepArgs {
   uint8_t* __restrict__ done;     // [N] or null
   T* __restrict__ term_obs;       // [N][D] or null
   const uint8_t* __restrict__ reset_mask;  // reset kernel only
+  unsigned long long* __restrict__ debug;  // diagnostic stamp builds only (else null)
 };
 
 // ----------------------------------------------------------------------------------------
@@ -246,8 +247,63 @@ template <typename T> __device__ __forceinline__ V3<T> rtmul(const T (&R)[9], V3
 
 __device__ __forceinline__ double sqrt_t(double x) { return sqrt(x); }
 __device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
-__device__ __forceinline__ void sincos_t(double x, double& s, double& c) { sincos(x, &s, &c); }
-__device__ __forceinline__ void sincos_t(float x, float& s, float& c) { sincosf(x, &s, &c); }
+// sin and cos of a joint angle.  Joint angles stay within a few 1e4 rad even for a spinning
+// periodic joint over a 100 000-step episode, so the argument reduction is the two-FMA
+// Cody-Waite form (exact product k*C1, FMA rounding relative to the small remainder) with the
+// library routine as the wave-uniform fallback beyond 2^19*pi/2; the kernels are the classical
+// minimax polynomials on [-pi/4, pi/4] (fdlibm k_sin / k_cos coefficients), ~1 ulp.
+__device__ __forceinline__ bool sincos_in_range(double x) { return fabs(x) < 8.2e5; }
+__device__ __forceinline__ bool sincos_in_range(float) { return false; }   // f32: library routine
+__device__ __forceinline__ void sincos_lib(double x, double& s, double& c) { sincos(x, &s, &c); }
+__device__ __forceinline__ void sincos_lib(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
+  const double k = __builtin_rint(x * 0x1.45f306dc9c883p-1);          // x * 2/pi
+  double r = __builtin_fma(-k, 0x1.921fb54442d18p+0, x);               // pi/2 = C1 + C2 + ...
+  r = __builtin_fma(-k, 0x1.1a62633145c07p-54, r);
+  const double z = r * r;
+  double ps = 0x1.5d93a5acfd57cp-33;                                    // S6
+  ps = __builtin_fma(ps, z, -0x1.ae5e68a2b9cebp-26);
+  ps = __builtin_fma(ps, z, 0x1.71de357b1fe7dp-19);
+  ps = __builtin_fma(ps, z, -0x1.a01a019c161d5p-13);
+  ps = __builtin_fma(ps, z, 0x1.111111110f8a6p-7);
+  ps = __builtin_fma(ps, z, -0x1.5555555555549p-3);
+  const double sr = __builtin_fma(r * z, ps, r);
+  double pc = -0x1.8fae9be8838d4p-37;                                   // C6
+  pc = __builtin_fma(pc, z, 0x1.1ee9ebdb4b1c4p-29);
+  pc = __builtin_fma(pc, z, -0x1.27e4f809c52adp-22);
+  pc = __builtin_fma(pc, z, 0x1.a01a019cb1590p-16);
+  pc = __builtin_fma(pc, z, -0x1.6c16c16c15177p-10);
+  pc = __builtin_fma(pc, z, 0x1.555555555554cp-5);
+  const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+  const int n = (int)k;
+  const double a = (n & 1) ? cr : sr, b = (n & 1) ? sr : cr;
+  s = (n & 2) ? -a : a;
+  c = ((n + 1) & 2) ? -b : b;
+}
+
+// Reciprocal / reciprocal square root by the hardware estimate plus Newton steps (~1 ulp), an
+// order of magnitude fewer instructions than the correctly rounded divide / sqrt.  Used in the
+// physics iteration only; the epilogue keeps IEEE division (bit parity with numpy).
+__device__ __forceinline__ double rcp_t(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float rcp_t(float x) { return 1.0f / x; }
+__device__ __forceinline__ double rsqrt_t(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  // r <- r * (1.5 - 0.5 x r^2), twice
+  r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+  r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+__device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
+
+// finite test on the bit pattern: immune to no-NaN assumptions of the optimiser
+__device__ __forceinline__ bool finite_t(double x) { return ((__double_as_longlong(x) >> 52) & 0x7ff) != 0x7ff; }
+__device__ __forceinline__ bool finite_t(float x) { return ((__float_as_int(x) >> 23) & 0xff) != 0xff; }
 
 // symmetric 3x3 stored as xx xy xz yy yz zz
 template <typename T> __device__ __forceinline__ V3<T> symmul(const T (&S)[6], V3<T> v) {
@@ -323,6 +379,23 @@ struct Params<T, MD, true> {
   __device__ __forceinline__ T gravity() const { return g; }
 };
 
+// Diagnostic phase stamps (separate build with -DOS2R_STAMPS, never in the shipped library):
+// shader-clock ticks per phase are summed per wave and written by lane 0 to a debug buffer that
+// nothing else reads (cdna_hip_programming.md, "In-kernel stamps").
+#ifdef OS2R_STAMPS
+#define OS2R_STAMP(idx)                                                                        \
+  do {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    unsigned long long t_;                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    stamps[idx] += t_ - stamp_prev;                                                            \
+    stamp_prev = t_;                                                                           \
+  } while (0)
+#else
+#define OS2R_STAMP(idx) do { } while (0)
+#endif
+
 // Opaque copy: a fresh SSA value the optimiser cannot merge with earlier uses.  Used to
 // *re*-compute cheap quantities (a joint rotation is 12 FMAs) instead of holding them in
 // registers across the whole physics iteration: fp64 state is register hungry and anything
@@ -350,20 +423,33 @@ __device__ __forceinline__ void joint_rotation(const MD& md, int i, T s_, T c_, 
 template <typename T, typename MD, bool CONTACT, bool DR>
 __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& par,
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T tau_hip, T tau_knee, T dt, T erp,
-                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds) {
+                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds,
+                                        const T* __restrict__ cand_lds
+#ifdef OS2R_STAMPS
+                                        , unsigned long long (&stamps)[12], unsigned long long& stamp_prev
+#endif
+                                        ) {
   constexpr int NQ = MD::NQ;
   constexpr unsigned CMASK = CONTACT ? MD::CMASK : 0u;
-#ifdef OS2R_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef OS2R_MARK
-  asm volatile("; SEC_1_sincos");
-#endif
+  const T inv_dt = rcp_t(dt);
   // ---- 1. sin/cos of the joint angles; rotations are rebuilt from them where needed ----
   T sn[NQ], cs[NQ];
+  {
+    // one wave-wide range check for all joints, so the five evaluations are straight-line code
+    // the scheduler can interleave (each is a long dependent chain on its own)
+    bool ok = true;
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) sincos_t(q[i], sn[i], cs[i]);
+    for (int i = 0; i < NQ; ++i) ok = ok && sincos_in_range(q[i]);
+    if (__ballot(!ok) == 0ull) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) sincos_fast(q[i], sn[i], cs[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) sincos_lib(q[i], sn[i], cs[i]);
+    }
+  }
 
+  OS2R_STAMP(0);
   // Per-lane LDS slots (slot-major: lds[slot * 64 + lane], conflict free).  During the
   // articulated-body passes they hold the per-joint quantities that must survive from one pass
   // to the next (body velocities, U = I^A S, 1/D, u); afterwards the same storage holds the
@@ -375,12 +461,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   auto ldv = [&](int base, int i) { return mk(L(base + 3 * i), L(base + 3 * i + 1), L(base + 3 * i + 2)); };
   auto stv = [&](int base, int i, V3<T> x) { L(base + 3 * i) = x.x; L(base + 3 * i + 1) = x.y; L(base + 3 * i + 2) = x.z; };
 
-#ifdef OS2R_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef OS2R_MARK
-  asm volatile("; SEC_2a_vel");
-#endif
   // ---- 2a. body velocities (body coordinates), outward ----
   {
     V3<T> w = mk<T>(0, 0, 0), v = mk<T>(0, 0, 0);
@@ -400,21 +480,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
   }
 
-#ifdef OS2R_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef OS2R_MARK
-  asm volatile("; SEC_2b_inward");
-#endif
   // ---- 2b. articulated inertias and bias forces, inward ----
   {
     ArtInertia<T> acc;     // children's contribution, in the current body's frame
     V3<T> pn, pf;          // children's bias force [moment; force]
 #pragma unroll
     for (int i = NQ - 1; i >= 0; --i) {
-#ifdef OS2R_SCHED_BARRIER
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       const int ax = md.axis(i);
       const V3<T> w = ldv(kW, i), v = ldv(kV, i);
       // rigid-body inertia of body i about its frame origin
@@ -451,7 +522,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       const V3<T> Ul = mk(I.H[3 * ax], I.H[3 * ax + 1], I.H[3 * ax + 2]);
       const T damp = par.damping(i);
       const T D = comp(Ua, ax) + dt * damp;
-      const T Dinv = T(1) / D;
+      const T Dinv = rcp_t(D);
       T tau = T(0);
       if (i == md.act_dof(0)) tau = tau_hip;
       if (i == md.act_dof(1)) tau = tau_knee;
@@ -522,12 +593,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
   }
 
-#ifdef OS2R_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef OS2R_MARK
-  asm volatile("; SEC_2c_outward");
-#endif
   // ---- 2c. accelerations, outward; the base accelerates by -g (gravity as a fictitious force) ----
   T vs[NQ];  // predicted velocity v* = qd + dt*qdd
   {
@@ -550,51 +615,66 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
   }
 
-#ifdef OS2R_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef OS2R_MARK
-  asm volatile("; SEC_3_minv");
-#endif
+  OS2R_STAMP(1);
   // ---- 3. inverse of (M + dt*diag(d)): unit-torque sweeps, upper triangle ----
+  // Column k is the response to a unit torque at joint k.  All columns are swept together,
+  // joint by joint, so every joint rotation, U_i and 1/D_i is fetched once per pass.
   T Mi[NQ][NQ];
+  {
+    T uk[NQ][NQ];            // uk[k][i]: joint-space force of column k at joint i (i <= k)
+    V3<T> pn_[NQ], pf_[NQ];  // bias force of column k, expressed in the current body
+    // inward: bodies NQ-1 .. 0
 #pragma unroll
-  for (int k = 0; k < NQ; ++k) {
-    T uk[NQ];
-    uk[k] = T(1);
-    const T dk = L(kDi + k);
-    V3<T> pn_ = dk * ldv(kUa, k), pf_ = dk * ldv(kUl, k);
-#pragma unroll
-    for (int i = k - 1; i >= 0; --i) {
-      // bias force of body i+1 expressed in body i
-      const V3<T> r = mk(md.rpos(i + 1, 0), md.rpos(i + 1, 1), md.rpos(i + 1, 2));
-      T Ri[9];
-      joint_rotation<T>(md, i + 1, sn[i + 1], cs[i + 1], Ri);
-      const V3<T> f = rmul(Ri, pf_);
-      const V3<T> n = rmul(Ri, pn_) + cross(r, f);
-      uk[i] = -comp(n, md.axis(i));
-      const T s = uk[i] * L(kDi + i);
-      pn_ = n + s * ldv(kUa, i);
-      pf_ = f + s * ldv(kUl, i);
-    }
-    V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, 0);
-#pragma unroll
-    for (int i = 0; i <= k; ++i) {
-      if (i > 0) {
-        const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
+    for (int i = NQ - 1; i >= 0; --i) {
+      const V3<T> Ua = ldv(kUa, i), Ul = ldv(kUl, i);
+      const T di = L(kDi + i);
+      // column i starts here with a unit torque
+      uk[i][i] = T(1);
+      // columns k > i arrive from body i+1: express in body i, project on the joint
+      if (i < NQ - 1) {
+        const V3<T> r = mk(md.rpos(i + 1, 0), md.rpos(i + 1, 1), md.rpos(i + 1, 2));
         T Ri[9];
-        joint_rotation<T>(md, i, sn[i], cs[i], Ri);
-        const V3<T> na = rtmul(Ri, aa);
-        al = rtmul(Ri, al + cross(aa, r));
-        aa = na;
+        joint_rotation<T>(md, i + 1, sn[i + 1], cs[i + 1], Ri);
+#pragma unroll
+        for (int k = i + 1; k < NQ; ++k) {
+          const V3<T> f = rmul(Ri, pf_[k]);
+          const V3<T> n = rmul(Ri, pn_[k]) + cross(r, f);
+          uk[k][i] = -comp(n, md.axis(i));
+          const T s_ = uk[k][i] * di;
+          pn_[k] = n + s_ * Ua;
+          pf_[k] = f + s_ * Ul;
+        }
       }
-      const T x = (uk[i] - dot(ldv(kUa, i), aa) - dot(ldv(kUl, i), al)) * L(kDi + i);
-      Mi[i][k] = x;
-      Mi[k][i] = x;
-      add_comp(aa, md.axis(i), x);
+      pn_[i] = di * Ua;
+      pf_[i] = di * Ul;
+    }
+    // outward: accelerations of every column, bodies 0 .. k
+    V3<T> aa[NQ], al[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) { aa[k] = mk<T>(0, 0, 0); al[k] = mk<T>(0, 0, 0); }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const V3<T> Ua = ldv(kUa, i), Ul = ldv(kUl, i);
+      const T di = L(kDi + i);
+      T Ri[9];
+      const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
+      if (i > 0) joint_rotation<T>(md, i, sn[i], cs[i], Ri);
+#pragma unroll
+      for (int k = i; k < NQ; ++k) {
+        if (i > 0) {
+          const V3<T> na = rtmul(Ri, aa[k]);
+          al[k] = rtmul(Ri, al[k] + cross(aa[k], r));
+          aa[k] = na;
+        }
+        const T x = (uk[k][i] - dot(Ua, aa[k]) - dot(Ul, al[k])) * di;
+        Mi[i][k] = x;
+        Mi[k][i] = x;
+        add_comp(aa[k], md.axis(i), x);
+      }
     }
   }
 
+  OS2R_STAMP(2);
   // ---- 4. whitening: Minv = Lc Lc^T (Cholesky, lower), y = Lc^-1 v ----
   // The constraint rows are solved in the coordinates y: for a row with Jacobian J_r,
   // J_r v = G_r y and the velocity response Minv J_r^T dl = Lc (G_r^T dl) with G_r = J_r Lc, so one
@@ -609,15 +689,16 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   auto Gs = [&](int b, int row, int k) -> T& { return L(kG + 3 * b * (b + 1) / 2 + row * (b + 1) + k); };
   T y[NQ];
   T idj[NQ];  // reciprocal of Minv[j][j] = |row j of Lc|^2 (joint friction rows)
+  T Lc[NQ][NQ];  // lower triangle, also mirrored to LDS for the contact-row setup
   {
-    T Lc[NQ][NQ], Ldi[NQ];
+    T Ldi[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       T sdiag = Mi[j][j];
 #pragma unroll
       for (int k = 0; k < j; ++k) sdiag -= Lc[j][k] * Lc[j][k];
-      Lc[j][j] = sqrt_t(sdiag);
-      Ldi[j] = T(1) / Lc[j][j];
+      Ldi[j] = rsqrt_t(sdiag);
+      Lc[j][j] = sdiag * Ldi[j];
       Lcs(j, j) = Lc[j][j];
 #pragma unroll
       for (int i = j + 1; i < NQ; ++i) {
@@ -627,7 +708,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         Lc[i][j] = sod * Ldi[j];
         Lcs(i, j) = Lc[i][j];
       }
-      idj[j] = Mi[j][j] > T(0) ? T(1) / Mi[j][j] : T(0);
+      idj[j] = Mi[j][j] > T(0) ? rcp_t(Mi[j][j]) : T(0);
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -641,9 +722,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
   for (int i = 0; i < NQ; ++i) y0[i] = y[i];
 
-#ifdef OS2R_MARK
-  asm volatile("; SEC_5_contacts");
-#endif
+  OS2R_STAMP(3);
   // ---- 5. ground contact candidates -> one point contact per body ----
   T dn[NB], dx[NB], dy[NB], erv[NB];  // dn/dx/dy: reciprocal of J Minv J^T = |G_r|^2 per row (0: row off)
   bool act[NB];
@@ -677,26 +756,61 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       aw[b] = mk(Rw[ax], Rw[3 + ax], Rw[6 + ax]);
       jo[b] = mk(ow[0], ow[1], ow[2]);
       if (!((CMASK >> b) & 1u)) continue;
+      OS2R_STAMP(4);
       const int k0 = md.cand_begin(b), k1 = md.cand_begin(b + 1);
       T W = 0, sx = 0, sy = 0, sz = 0;
-#pragma unroll 4
-      for (int k = k0; k < k1; ++k) {
-        const T px = md.cand(k, 0), py = md.cand(k, 1), pz = md.cand(k, 2);
-        const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
-        const T wgt = z < margin ? margin - z : T(0);
-        W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+      // Candidate table: wave-shared LDS copy (broadcast reads).  The scan is software
+      // pipelined by hand -- two register buffers of 4 candidates, the next chunk is requested
+      // before the current one is consumed -- because at one wave per SIMD nothing else hides
+      // the LDS latency.
+      {
+        constexpr int CH = 4;
+        auto fetch = [&](int k, T (&d)[3 * CH]) {
+#pragma unroll
+          for (int j = 0; j < 3 * CH; ++j) d[j] = cand_lds[3 * k + j];
+        };
+        auto consume = [&](const T (&d)[3 * CH]) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            const T px = d[3 * c], py = d[3 * c + 1], pz = d[3 * c + 2];
+            const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
+            const T wgt = z < margin ? margin - z : T(0);
+            W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+          }
+        };
+        T bufA[3 * CH], bufB[3 * CH];
+        int k = k0;
+        const int kpair = k0 + ((k1 - k0) / (2 * CH)) * (2 * CH);   // whole pairs of chunks
+        if (k < kpair) {
+          fetch(k, bufA);
+#pragma unroll 1
+          for (; k < kpair; k += 2 * CH) {
+            fetch(k + CH, bufB);
+            consume(bufA);
+            if (k + 2 * CH < kpair) fetch(k + 2 * CH, bufA);
+            consume(bufB);
+          }
+        }
+#pragma unroll 1
+        for (; k < k1; ++k) {   // remainder (none for the reference's models: 8 | count)
+          const T px = cand_lds[3 * k], py = cand_lds[3 * k + 1], pz = cand_lds[3 * k + 2];
+          const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
+          const T wgt = z < margin ? margin - z : T(0);
+          W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+        }
       }
+      OS2R_STAMP(5);
       act[b] = W > T(0);
       wave_act[b] = __ballot(act[b]) != 0ull;
       if (wave_act[b]) {
-        const T iw = act[b] ? T(1) / W : T(0);
+        const T iw = act[b] ? rcp_t(W) : T(0);
         const V3<T> pc = mk(sx * iw, sy * iw, sz * iw);
         const V3<T> pw = rmul(Rw, pc) + jo[b];
         // gap-based non-penetration (Stewart-Trinkle): an open gap may close within the step,
         // a penetration is pushed out at the capped error-reduction velocity
         const T gap = pw.z;
-        const T e = erp * (-gap) / dt;
-        erv[b] = gap >= T(0) ? -gap / dt : (e > max_erv ? max_erv : e);
+        const T e = erp * (-gap) * inv_dt;
+        erv[b] = gap >= T(0) ? -gap * inv_dt : (e > max_erv ? max_erv : e);
         T Jn[NQ], Jx[NQ], Jy[NQ];  // Jacobian rows of the contact point: normal z, tangents x, y
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -719,14 +833,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           }
         }
         // reciprocals once per iteration of the physics, not once per row update
-        dn[b] = sdn > T(0) ? T(1) / sdn : T(0); dx[b] = sdx > T(0) ? T(1) / sdx : T(0); dy[b] = sdy > T(0) ? T(1) / sdy : T(0);
+        dn[b] = sdn > T(0) ? rcp_t(sdn) : T(0); dx[b] = sdx > T(0) ? rcp_t(sdx) : T(0); dy[b] = sdy > T(0) ? rcp_t(sdy) : T(0);
       }
     }
   }
 
-#ifdef OS2R_MARK
-  asm volatile("; SEC_6_pgs");
-#endif
+  OS2R_STAMP(6);
   // ---- 6. projected Gauss-Seidel on the (whitened) velocities ----
   T ln[NB], lx[NB], ly[NB], lf[NQ];
 #pragma unroll
@@ -748,10 +860,11 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // at mu ~ 1 (Painleve) and is kept for experiments only.
   auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi) {
     T g[NQ];
-    T res = -target;
+    T r0 = -target, r1 = 0;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (k <= b) { g[k] = Gs(b, row, k); res += g[k] * y[k]; }
+      if (k <= b) { g[k] = Gs(b, row, k); if (k & 1) r1 += g[k] * y[k]; else r0 += g[k] * y[k]; }
+    const T res = r0 + r1;
     T lam = l - res * rd;
     lam = lam < lo ? lo : lam;
     lam = lam > hi ? hi : lam;
@@ -766,11 +879,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       // joint Coulomb friction row: J = e_j, G = row j of Lc, d = Minv[j][j]
-      T g[NQ];
-      T res = 0;
+      // (two partial sums: the sweep is a chain of dependent operations, keep it short)
+      T r0 = 0, r1 = 0;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
-        if (k <= j) { g[k] = Lcs(j, k); res += g[k] * y[k]; }
+        if (k <= j) { if (k & 1) r1 += Lc[j][k] * y[k]; else r0 += Lc[j][k] * y[k]; }
+      const T res = r0 + r1;
       T lam = lf[j] - res * idj[j];
       lam = lam < -fb[j] ? -fb[j] : lam;
       lam = lam > fb[j] ? fb[j] : lam;
@@ -779,7 +893,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       lf[j] = lam;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
-        if (k <= j) y[k] += g[k] * dl;
+        if (k <= j) y[k] += Lc[j][k] * dl;
     }
   };
   const T kInf = T(1e300) * T(1e300);
@@ -792,6 +906,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
     joint_rows();
   }
+  OS2R_STAMP(7);
   T limfix[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) limfix[b] = par.mu(b) * ln[b];
@@ -807,28 +922,24 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
     joint_rows();
   }
+  OS2R_STAMP(8);
   // back to joint velocities: v += Lc (y - y0)
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     T acc_ = 0;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (k <= i) acc_ += Lcs(i, k) * (y[k] - y0[k]);
+      if (k <= i) acc_ += Lc[i][k] * (y[k] - y0[k]);
     vs[i] += acc_;
   }
 
-#ifdef OS2R_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef OS2R_MARK
-  asm volatile("; SEC_7_integrate");
-#endif
   // ---- 7. semi-implicit Euler ----
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     qd[i] = vs[i];
     q[i] += dt * vs[i];
   }
+  OS2R_STAMP(9);
 }
 
 }  // namespace os2r

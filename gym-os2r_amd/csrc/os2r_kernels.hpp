@@ -58,7 +58,7 @@ __device__ __forceinline__ void observe(TaskPtr<T> ts, const T (&q)[NQ], const T
     if (kind == OS2R_OBS_POS_PERIODIC_NORM || kind == OS2R_OBS_POS_PERIODIC_RAW) x = wrap_pi(x);
     // done: the reference tests the observation against reset_space; done_lo/done_hi are the
     // exact pre-images of that test on x (host-side bisection), NaN counts as done
-    if (!(x >= ts->done_lo[d] && x <= ts->done_hi[d])) done = true;
+    if (x < ts->done_lo[d] || x > ts->done_hi[d] || !finite_t(x)) done = true;   // NaN counts as done
     T o = x;
     if (kind == OS2R_OBS_POS_NORM || kind == OS2R_OBS_POS_PERIODIC_NORM || kind == OS2R_OBS_TORQUE_NORM) {
       const T lo = ts->obs_low[d], hi = ts->obs_high[d];
@@ -294,6 +294,8 @@ constexpr int lds_words() {
   constexpr int m = rows > aba ? rows : aba;
   return kWave * (m > OS2R_MAX_OBS ? m : OS2R_MAX_OBS);
 }
+// wave-shared copy of the contact candidate table, behind the per-lane slots
+constexpr int kCandWords = 3 * OS2R_MAX_CAND;
 
 template <typename T, typename MD>
 __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
@@ -304,12 +306,18 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 template <typename T, typename MD, bool CONTACT, bool DR>
 __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   constexpr int NQ = MD::NQ;
-  __shared__ T tile[lds_words<NQ>()];
+  __shared__ T tile[lds_words<NQ>() + (CONTACT && MD::CMASK != 0u ? kCandWords : 0)];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
   const long long e = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
   const MD md = make_model<T, MD>(A);
+  T* cand_lds = tile + lds_words<NQ>();
+  if constexpr (CONTACT && MD::CMASK != 0u) {
+    const int nc3 = 3 * md.cand_begin(NQ);
+    for (int k = lane; k < nc3; k += kWave) cand_lds[k] = md.cand(k / 3, k % 3);
+    __syncthreads();
+  }
   const TaskPtr<T> ts = as_const(A.task);
 
   T q[NQ], qd[NQ];
@@ -345,15 +353,26 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
     asy = tau_knee / md.max_torque(1);
   }
 
+#ifdef OS2R_STAMPS
+  unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters, tile);
+    substep<T, MD, CONTACT, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters, tile, cand_lds
+#ifdef OS2R_STAMPS
+                                , stamps, stamp_prev
+#endif
+    );
   }
+#ifdef OS2R_STAMPS
+  if (A.debug && lane == 0)
+    for (int k = 0; k < 12; ++k) A.debug[blockIdx.x * 12 + k] = stamps[k];
+#endif
   __syncthreads();
 
   bool bad = false;
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) bad = bad || !(fabs_t(q[i]) < T(1e30)) || !(fabs_t(qd[i]) < T(1e30));
+  for (int i = 0; i < NQ; ++i) bad = bad || !finite_t(q[i]) || !finite_t(qd[i]) || fabs_t(q[i]) > T(1e30) || fabs_t(qd[i]) > T(1e30);
 
   const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
   T obs[OS2R_MAX_OBS];

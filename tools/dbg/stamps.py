@@ -1,0 +1,50 @@
+"""Diagnostic: where does a physics iteration spend its cycles?  Needs `make -C gym-os2r_amd/csrc stamps`.
+Loads libos2r_stamps.so (in-kernel s_memtime stamps per phase) and prints each phase's share of
+the shader-clock ticks of one env-step, averaged over waves.  Shares only: the stamp build is
+slower than the real kernel (its fences forbid overlap)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import gym_os2r_amd  # noqa: F401
+from gym_os2r_amd import _lib
+_lib.LIB_PATH = os.path.join(ROOT, "gym-os2r_amd", "libos2r_stamps.so")
+import bench
+
+PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y)", "contact: forward kinematics",
+          "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "-", "-"]
+
+
+def main():
+    class A:  # bench.build_config arguments
+        workload = sys.argv[1] if len(sys.argv) > 1 else "C4"
+        envs_per_gpu = 65536; dtype = "f64"; seed = 42; pgs_iters = 20; pgs_normal_iters = 8
+    cfg, model, spec = bench.build_config(A, 0, 1)
+    from gym_os2r_amd.sim import HipSim
+    sim = HipSim(cfg)
+    lib = _lib.load()
+    nwg = (cfg.num_envs + 63) // 64
+    buf = torch.zeros(nwg * 12, dtype=torch.int64, device="cuda")
+    lib.os2r_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
+    for _ in range(50):
+        sim.step(None, want_terminal=False)
+    assert lib.os2r_debug_set_stamp_buffer(sim._h, C.c_void_p(buf.data_ptr())) == 0
+    acc = np.zeros(12)
+    for _ in range(20):
+        sim.step(None, want_terminal=False)
+        torch.cuda.synchronize()
+        acc += buf.cpu().numpy().reshape(nwg, 12).mean(axis=0)
+    acc /= 20
+    tot = acc.sum()
+    print(f"workload {A.workload}: {tot:.0f} ticks per env-step per wave ({tot / cfg.substeps:.0f} per physics iteration)")
+    for name, v in zip(PHASES, acc):
+        print(f"  {name:42s} {v / cfg.substeps:9.0f} ticks/iter  {100 * v / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()
