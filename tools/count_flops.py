@@ -55,7 +55,7 @@ def flops_substep(nq, ncand, contacts_mean, cols_mean, sweeps_n, sweeps_all, con
     return f
 
 
-def measure_contacts(mode, dr, n=1024, steps=150, seed=42):
+def measure_contacts(mode, dr, n=1024, steps=1100, seed=42):
     from helpers import make_config
     from gym_os2r_amd import abi
     from oracle import oracle_py as o
@@ -66,7 +66,7 @@ def measure_contacts(mode, dr, n=1024, steps=150, seed=42):
     tot, cols, cnt = 0.0, 0.0, 0
     for t in range(steps):
         sim.step(None)
-        if t % 10 == 9:
+        if t >= 100 and t % 25 == 24:
             q, qd = sim.get_state()
             for e in range(0, n, 8):
                 _, _, rw, ow = o.dynamics(cfg.model, q[:, e], qd[:, e], np.zeros(cfg.model.nq))
@@ -95,7 +95,7 @@ def main():
                 "mean_bodies_in_contact": round(cm, 3), "mean_jacobian_columns": round(colm, 3),
                 "stages_per_physics_iteration": {k: round(v, 1) for k, v in stages.items()},
                 "source": "tools/count_flops.py: analytic count of the specification; contact activity measured "
-                          "with the CPU oracle on 1024 envs x 150 random-action env-steps of the workload"}
+                          "with the CPU oracle on 1024 envs over the bench's 100 warm-up + 1000 timed random-action env-steps"}
         print(name, "flops/env-step", round(total), "contacts", round(cm, 2))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     with open(os.path.join(ROOT, "profiles", "flops.json"), "w") as f:
