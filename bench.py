@@ -111,10 +111,14 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pgs-iters", type=int, default=20)
-    ap.add_argument("--pgs-normal-iters", type=int, default=8)
+    ap.add_argument("--pgs-normal-iters", type=int, default=3)
     ap.add_argument("--cpu-envs", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-time reduction (nccl = RCCL; gloo lets several "
+                         "ranks share one GPU when rehearsing the multi-rank path)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
     if args.envs_per_gpu is None:
         args.envs_per_gpu = 4096 if args.workload == "C2" else 65536
@@ -135,10 +139,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the stepper has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     cfg, model, spec = build_config(args, rank, world)
     sim = HipSim(cfg, device=f"cuda:{local_rank}")
@@ -156,7 +165,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 

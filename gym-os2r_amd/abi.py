@@ -49,6 +49,8 @@ class Os2rModel(C.Structure):
         ("ncand", C.c_int32),
         ("cand_body", C.c_int32 * MAX_CAND),
         ("cand_p", (C.c_double * 3) * MAX_CAND),
+        ("cand_center", (C.c_double * 3) * MAX_DOF),
+        ("cand_radius", C.c_double * MAX_DOF),
     ]
 
 
@@ -149,6 +151,19 @@ def model_struct(m: Mapping) -> Os2rModel:
         s.cand_body[k] = b
         for j in range(3):
             s.cand_p[k][j] = float(m["cand_p"][k][j])
+    # bounding sphere of each body's candidates (centre = mean point): lets the kernels skip the
+    # scan of a body whose sphere is clear of the ground for every lane of a wave
+    import numpy as _np
+    pts = _np.array([[s.cand_p[k][j] for j in range(3)] for k in range(s.ncand)]).reshape(-1, 3)
+    bodies = _np.array([s.cand_body[k] for k in range(s.ncand)], dtype=int)
+    for b in range(nq):
+        sel = pts[bodies == b]
+        if len(sel):
+            c = sel.mean(axis=0)
+            r = float(_np.max(_np.linalg.norm(sel - c, axis=1))) * (1 + 1e-12) + 1e-12
+            for j in range(3):
+                s.cand_center[b][j] = float(c[j])
+            s.cand_radius[b] = r
     return s
 
 
@@ -191,7 +206,7 @@ def task_struct(t: Mapping) -> Os2rTaskSpec:
 
 def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = F64,
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
-                  dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 8,
+                  dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 3,
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
                   contact_margin: float = 1e-3) -> Os2rConfig:
     c = Os2rConfig()

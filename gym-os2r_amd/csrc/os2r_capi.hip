@@ -87,6 +87,11 @@ void fill_model(const Os2rModel& m_in, bool contact, DevModel<T>& d) {
   d.cand_begin[OS2R_MAX_DOF] = k;
   for (int c = 0; c < m.ncand; ++c)
     for (int j = 0; j < 3; ++j) d.cand_p[c][j] = (T)m.cand_p[c][j];
+  for (int b = 0; b < OS2R_MAX_DOF; ++b) {
+    for (int j = 0; j < 3; ++j) d.cand_center[b][j] = (T)m.cand_center[b][j];
+    // a zero radius (model built without spheres) must never cull: make it cover everything
+    d.cand_radius[b] = m.cand_radius[b] > 0.0 ? (T)(m.cand_radius[b] * 1.000001) : (T)1e30;
+  }
 }
 
 template <typename T>

@@ -55,6 +55,8 @@ struct DevModel {
   T gravity_z;
   int cand_begin[OS2R_MAX_DOF + 1];  // candidates of body b: [cand_begin[b], cand_begin[b+1])
   T cand_p[OS2R_MAX_CAND][3];
+  T cand_center[OS2R_MAX_DOF][3];    // bounding sphere of body b's candidates
+  T cand_radius[OS2R_MAX_DOF];
 };
 
 template <typename T>
@@ -154,6 +156,8 @@ struct RtModel {
   __device__ __forceinline__ T max_torque(int k) const { return p->max_torque[k]; }
   __device__ __forceinline__ int cand_begin(int b) const { return p->cand_begin[b]; }
   __device__ __forceinline__ T cand(int k, int j) const { return p->cand_p[k][j]; }
+  __device__ __forceinline__ T cand_center(int b, int j) const { return p->cand_center[b][j]; }
+  __device__ __forceinline__ T cand_radius(int b) const { return p->cand_radius[b]; }
 };
 
 template <typename T, int ID>
@@ -175,6 +179,8 @@ struct StModel {
   __device__ __forceinline__ constexpr T max_torque(int k) const { return (T)Tb::max_torque[k]; }
   __device__ __forceinline__ constexpr int cand_begin(int b) const { return Tb::cand_begin[b]; }
   __device__ __forceinline__ constexpr T cand(int k, int j) const { return (T)Tb::cand_p[k][j]; }
+  __device__ __forceinline__ constexpr T cand_center(int b, int j) const { return (T)Tb::cand_center[b][j]; }
+  __device__ __forceinline__ constexpr T cand_radius(int b) const { return (T)Tb::cand_radius[b]; }
 };
 
 // ----------------------------------------------------------------------------------------
@@ -759,6 +765,11 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       OS2R_STAMP(4);
       const int k0 = md.cand_begin(b), k1 = md.cand_begin(b + 1);
       T W = 0, sx = 0, sy = 0, sz = 0;
+      // skip the scan when the body's candidate sphere is clear of the contact band for every
+      // lane of the wave (no candidate can have z < margin then, so W stays 0 exactly)
+      const T zc = Rw[6] * md.cand_center(b, 0) + Rw[7] * md.cand_center(b, 1) + Rw[8] * md.cand_center(b, 2) + ow[2];
+      const bool near = zc - md.cand_radius(b) < margin;
+      if (__ballot(near) != 0ull)
       // Candidate table: wave-shared LDS copy (broadcast reads).  The scan is software
       // pipelined by hand -- two register buffers of 4 candidates, the next chunk is requested
       // before the current one is consumed -- because at one wave per SIMD nothing else hides
@@ -833,7 +844,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           }
         }
         // reciprocals once per iteration of the physics, not once per row update
-        dn[b] = sdn > T(0) ? rcp_t(sdn) : T(0); dx[b] = sdx > T(0) ? rcp_t(sdx) : T(0); dy[b] = sdy > T(0) ? rcp_t(sdy) : T(0);
+        dn[b] = (act[b] && sdn > T(0)) ? rcp_t(sdn) : T(0);
+        dx[b] = (act[b] && sdx > T(0)) ? rcp_t(sdx) : T(0);
+        dy[b] = (act[b] && sdy > T(0)) ? rcp_t(sdy) : T(0);
       }
     }
   }
@@ -858,7 +871,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // unique velocity solution.  pgs_normal_iters == 0 selects the coupled pyramid (bounds follow
   // the current normal impulse inside the sweep), which is ill-posed for a slender leg sliding
   // at mu ~ 1 (Painleve) and is kept for experiments only.
-  auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi) {
+  // A row that is switched off has reciprocal rd == 0: lam = l - res*0 = l, and l already lies
+  // inside its box, so the row reproduces itself without any select.
+  auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper) {
     T g[NQ];
     T r0 = -target, r1 = 0;
 #pragma unroll
@@ -867,8 +882,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     const T res = r0 + r1;
     T lam = l - res * rd;
     lam = lam < lo ? lo : lam;
-    lam = lam > hi ? hi : lam;
-    lam = (act[b] && rd > T(0)) ? lam : l;
+    if (upper) lam = lam > hi ? hi : lam;
     const T dl = lam - l;
     l = lam;
 #pragma unroll
@@ -888,7 +902,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       T lam = lf[j] - res * idj[j];
       lam = lam < -fb[j] ? -fb[j] : lam;
       lam = lam > fb[j] ? fb[j] : lam;
-      lam = idj[j] > T(0) ? lam : lf[j];
       const T dl = lam - lf[j];
       lf[j] = lam;
 #pragma unroll
@@ -896,13 +909,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         if (k <= j) y[k] += Lc[j][k] * dl;
     }
   };
-  const T kInf = T(1e300) * T(1e300);
   const bool fixed_box = pgs_normal_iters > 0;
   for (int it = 0; it < pgs_normal_iters; ++it) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
-      if (wave_act[b]) contact_row(b, 0, erv[b], dn[b], ln[b], T(0), kInf);
+      if (wave_act[b]) contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
     }
     joint_rows();
   }
@@ -915,10 +927,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (!wave_act[b]) continue;
-      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), kInf);
+      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
       const T lim = fixed_box ? limfix[b] : par.mu(b) * ln[b];
-      contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim);
-      contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim);
+      contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true);
+      contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true);
     }
     joint_rows();
   }

@@ -77,6 +77,10 @@ static bool matches(const Os2rModel& m) {
     if (m.cand_body[c] != b) return false;
     for (int j = 0; j < 3; ++j) if (m.cand_p[c][j] != Tb::cand_p[c][j]) return false;
   }
+  for (int i = 0; i < Tb::nq; ++i) {
+    if (m.cand_radius[i] != Tb::cand_radius[i]) return false;
+    for (int j = 0; j < 3; ++j) if (m.cand_center[i][j] != Tb::cand_center[i][j]) return false;
+  }
   return true;
 }
 

@@ -50,7 +50,7 @@ class HipRuntime:
                  real_time_factor: float = float(np.finfo(np.float32).max), *,
                  num_envs: int = 1, device=None, seed: int = 0, dtype: str = "f64",
                  contact: bool = True, max_episode_steps: int = 0, env_offset: int = 0,
-                 pgs_iters: int = 20, pgs_normal_iters: int = 8, auto_reset: bool = True,
+                 pgs_iters: int = 20, pgs_normal_iters: int = 3, auto_reset: bool = True,
                  physics_engine=None, world: Optional[str] = None, **kwargs):
         steps = physics_rate / agent_rate
         if steps != int(steps):

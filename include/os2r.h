@@ -75,6 +75,8 @@ typedef struct Os2rModel {
   int32_t ncand;                       /* number of contact candidate points                 */
   int32_t cand_body[OS2R_MAX_CAND];    /* body index of each candidate, non-decreasing       */
   double cand_p[OS2R_MAX_CAND][3];     /* candidate position in its body frame [m]           */
+  double cand_center[OS2R_MAX_DOF][3]; /* bounding sphere of body i's candidates (body frame) */
+  double cand_radius[OS2R_MAX_DOF];    /*   used to skip the scan of a body far from the ground */
 } Os2rModel;
 
 /* observation slot kinds (gym_os2r/tasks/monopod.py:238-272, monopod_no_norm.py:222-246) */
