@@ -1,0 +1,49 @@
+// os2r_pybind.cpp — thin pybind11 module over the C-ABI of include/os2r.h.
+//
+// One function per entry point, integer addresses in (tensor.data_ptr(), ctypes.addressof of
+// the config struct, the raw hipStream_t), status codes out; no torch types, no logic.  The GIL is
+// released around every call.  gym_os2r_amd.sim uses it when OS2R_BINDING=pybind11 (default: ctypes).
+#include <pybind11/pybind11.h>
+
+#include <cstdint>
+
+#include "../../include/os2r.h"
+
+namespace py = pybind11;
+using addr = std::uintptr_t;
+
+static Os2rSim* H(addr h) { return reinterpret_cast<Os2rSim*>(h); }
+static void* P(addr a) { return reinterpret_cast<void*>(a); }
+
+PYBIND11_MODULE(_os2r_py, m) {
+  m.doc() = "pybind11 binding of libos2r.so (MI355X batched monopod stepper)";
+  const auto nogil = py::call_guard<py::gil_scoped_release>();
+  m.def("abi_version", &os2r_abi_version);
+  m.def("create", [](addr cfg) {
+    Os2rSim* s = nullptr;
+    int rc;
+    { py::gil_scoped_release rel; rc = os2r_create(reinterpret_cast<const Os2rConfig*>(cfg), &s); }
+    return py::make_tuple(rc, reinterpret_cast<addr>(s));
+  });
+  m.def("destroy", [](addr h) { return os2r_destroy(H(h)); }, nogil);
+  m.def("reset", [](addr h, addr mask, addr obs, addr st) { return os2r_reset(H(h), (const uint8_t*)P(mask), P(obs), P(st)); }, nogil);
+  m.def("step", [](addr h, addr act, addr obs, addr rew, addr done, addr term, addr st) {
+    return os2r_step(H(h), P(act), P(obs), P(rew), (uint8_t*)P(done), P(term), P(st)); }, nogil);
+  m.def("get_state", [](addr h, addr q, addr qd, addr st) { return os2r_get_state(H(h), P(q), P(qd), P(st)); }, nogil);
+  m.def("set_state", [](addr h, addr q, addr qd, addr st) { return os2r_set_state(H(h), P(q), P(qd), P(st)); }, nogil);
+  m.def("get_action_history", [](addr h, int w, addr o, addr st) { return os2r_get_action_history(H(h), w, P(o), P(st)); }, nogil);
+  m.def("set_action_history", [](addr h, int w, addr i, addr st) { return os2r_set_action_history(H(h), w, P(i), P(st)); }, nogil);
+  m.def("set_params", [](addr h, int f, addr s, addr st) { return os2r_set_params(H(h), f, P(s), P(st)); }, nogil);
+  m.def("get_params", [](addr h, int f, addr d, addr st) { return os2r_get_params(H(h), f, P(d), P(st)); }, nogil);
+  m.def("get_episode_info", [](addr h, addr s, addr e, addr p, addr st) {
+    return os2r_get_episode_info(H(h), (int32_t*)P(s), (uint32_t*)P(e), (uint8_t*)P(p), P(st)); }, nogil);
+  m.def("get_step_count", [](addr h) { uint64_t v = 0; int rc = os2r_get_step_count(H(h), &v); return py::make_tuple(rc, v); });
+  m.def("set_step_count", [](addr h, uint64_t v) { return os2r_set_step_count(H(h), v); });
+  m.def("bench_steps", [](addr h, int n, addr st) {
+    float ms = 0.f;
+    int rc;
+    { py::gil_scoped_release rel; rc = os2r_bench_steps(H(h), n, P(st), &ms); }
+    return py::make_tuple(rc, ms);
+  });
+  m.def("last_error", [](addr h) { return std::string(os2r_last_error(H(h))); });
+}

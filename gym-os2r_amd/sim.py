@@ -17,6 +17,75 @@ class Os2rError(RuntimeError):
     pass
 
 
+class _PybindLib:
+    """Adapter giving the pybind11 module (`_os2r_py`) the call shapes of the ctypes library, so the
+    rest of this file is binding-agnostic.  Selected with OS2R_BINDING=pybind11."""
+
+    def __init__(self):
+        import importlib
+        self.m = importlib.import_module("gym_os2r_amd._os2r_py")
+        if self.m.abi_version() != abi.ABI_VERSION:
+            raise ImportError("_os2r_py ABI version mismatch")
+
+    @staticmethod
+    def _a(x):
+        if x is None:
+            return 0
+        v = getattr(x, "value", x)
+        return 0 if v is None else int(v)
+
+    def os2r_create(self, cfg_ref, out_ref):
+        rc, h = self.m.create(C.addressof(cfg_ref._obj))
+        out_ref._obj.value = h
+        return rc
+
+    def os2r_destroy(self, h):
+        return self.m.destroy(self._a(h))
+
+    def os2r_reset(self, h, mask, obs, st):
+        return self.m.reset(self._a(h), self._a(mask), self._a(obs), self._a(st))
+
+    def os2r_step(self, h, act, obs, rew, done, term, st):
+        return self.m.step(self._a(h), self._a(act), self._a(obs), self._a(rew), self._a(done), self._a(term), self._a(st))
+
+    def os2r_get_state(self, h, q, qd, st):
+        return self.m.get_state(self._a(h), self._a(q), self._a(qd), self._a(st))
+
+    def os2r_set_state(self, h, q, qd, st):
+        return self.m.set_state(self._a(h), self._a(q), self._a(qd), self._a(st))
+
+    def os2r_get_action_history(self, h, w, o, st):
+        return self.m.get_action_history(self._a(h), int(w), self._a(o), self._a(st))
+
+    def os2r_set_action_history(self, h, w, i, st):
+        return self.m.set_action_history(self._a(h), int(w), self._a(i), self._a(st))
+
+    def os2r_set_params(self, h, f, s, st):
+        return self.m.set_params(self._a(h), int(f), self._a(s), self._a(st))
+
+    def os2r_get_params(self, h, f, d, st):
+        return self.m.get_params(self._a(h), int(f), self._a(d), self._a(st))
+
+    def os2r_get_episode_info(self, h, s, e, p, st):
+        return self.m.get_episode_info(self._a(h), self._a(s), self._a(e), self._a(p), self._a(st))
+
+    def os2r_get_step_count(self, h, out_ref):
+        rc, v = self.m.get_step_count(self._a(h))
+        out_ref._obj.value = v
+        return rc
+
+    def os2r_set_step_count(self, h, v):
+        return self.m.set_step_count(self._a(h), int(getattr(v, "value", v)))
+
+    def os2r_bench_steps(self, h, n, st, ms_ref):
+        rc, ms = self.m.bench_steps(self._a(h), int(n), self._a(st))
+        ms_ref._obj.value = ms
+        return rc
+
+    def os2r_last_error(self, h):
+        return self.m.last_error(self._a(h)).encode()
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -24,8 +93,12 @@ def _ptr(t: Optional[torch.Tensor]):
 class HipSim:
     """N environments resident on one GPU."""
 
-    def __init__(self, cfg: abi.Os2rConfig, device: Optional[torch.device] = None):
-        self._lib = _lib.load()
+    def __init__(self, cfg: abi.Os2rConfig, device: Optional[torch.device] = None, binding: Optional[str] = None):
+        import os
+        binding = binding or os.environ.get("OS2R_BINDING", "ctypes")
+        _lib.load()                                   # the C-ABI library must be there either way
+        self._lib = _PybindLib() if binding == "pybind11" else _lib.load()
+        self.binding = binding
         if not torch.cuda.is_available():
             raise Os2rError("no GPU visible: the stepper runs on MI355X only (no CPU fallback)")
         self.device = torch.device(device if device is not None else f"cuda:{cfg.device}")

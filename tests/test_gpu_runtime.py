@@ -145,3 +145,24 @@ def test_scenario_facade_drives_one_env(torch_mod, oracle):
     assert not model.set_joint_generalized_force_targets([1.0], ["no_such_joint"])
     assert world.to_gazebo().remove_model(model.name()) and not world.model_names()
     assert gz.close()
+
+
+def test_pybind11_and_ctypes_bindings_agree(torch_mod):
+    """Both bindings drive the same C-ABI: identical rollouts, bit for bit."""
+    from helpers import make_config
+    from gym_os2r_amd.sim import HipSim
+    cfg, _, _ = make_config("free_hip", "BalancingV2", True, num_envs=200, seed=3, reset_mode=abi.RESET_RANDOM,
+                            randomize_params=True, max_episode_steps=7)
+    a, b = HipSim(cfg, binding="ctypes"), HipSim(cfg, binding="pybind11")
+    assert b.binding == "pybind11"
+    for _ in range(12):
+        oa, ra, da, ta = a.step(None)
+        ob, rb, db, tb = b.step(None)
+    assert torch_mod.equal(oa, ob) and torch_mod.equal(ra, rb) and torch_mod.equal(da, db) and torch_mod.equal(ta, tb)
+    qa, qb = a.get_state(), b.get_state()
+    assert torch_mod.equal(qa[0], qb[0]) and torch_mod.equal(qa[1], qb[1])
+    assert a.step_count == b.step_count == 12
+    mask = torch_mod.ones(200, dtype=torch_mod.uint8, device="cuda")
+    assert torch_mod.equal(a.reset(mask), b.reset(mask))
+    assert b.bench_steps(2) > 0.0 and b.step_count == 14
+    a.close(); b.close()

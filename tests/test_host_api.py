@@ -235,3 +235,15 @@ def test_model_compiler_on_a_synthetic_urdf(tmp_path):
     assert abs(m["rfix"][1][4] - np.cos(1.57)) < 1e-16 and m["rfix"][1][4] != 0.0   # literal 1.57, not pi/2
     s = abi.model_struct(m)
     assert s.nq == 2 and s.ncand == 0
+
+
+def test_pybind11_module_mirrors_the_c_abi():
+    """The thin pybind11 module exposes one function per C-ABI entry point (no compute here)."""
+    import importlib
+    from gym_os2r_amd import _lib
+    m = importlib.import_module("gym_os2r_amd._os2r_py")
+    assert m.abi_version() == abi.ABI_VERSION
+    for sym in _lib.SYMBOLS:
+        assert hasattr(m, sym[len("os2r_"):]), sym
+    rc, handle = m.create(0)                       # null config: rejected, no device touched
+    assert rc == abi.ERR_INVALID and handle == 0 and "null config" in m.last_error(0)
