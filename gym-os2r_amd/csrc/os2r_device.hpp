@@ -307,6 +307,9 @@ __device__ __forceinline__ double rsqrt_t(double x) {
 }
 __device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
 
+__device__ __forceinline__ double fmax_t(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float fmax_t(float a, float b) { return fmaxf(a, b); }
+
 // finite test on the bit pattern: immune to no-NaN assumptions of the optimiser
 __device__ __forceinline__ bool finite_t(double x) { return ((__double_as_longlong(x) >> 52) & 0x7ff) != 0x7ff; }
 __device__ __forceinline__ bool finite_t(float x) { return ((__float_as_int(x) >> 23) & 0xff) != 0xff; }
@@ -785,7 +788,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           for (int c = 0; c < CH; ++c) {
             const T px = d[3 * c], py = d[3 * c + 1], pz = d[3 * c + 2];
             const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
-            const T wgt = z < margin ? margin - z : T(0);
+            const T wgt = fmax_t(margin - z, T(0));
             W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
           }
         };
@@ -806,7 +809,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         for (; k < k1; ++k) {   // remainder (none for the reference's models: 8 | count)
           const T px = cand_lds[3 * k], py = cand_lds[3 * k + 1], pz = cand_lds[3 * k + 2];
           const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
-          const T wgt = z < margin ? margin - z : T(0);
+          const T wgt = fmax_t(margin - z, T(0));
           W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
         }
       }
