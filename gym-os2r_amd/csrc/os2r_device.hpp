@@ -461,16 +461,17 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   OS2R_STAMP(0);
   // Per-lane LDS slots (slot-major: lds[slot * 64 + lane], conflict free).  During the
   // articulated-body passes they hold the per-joint quantities that must survive from one pass
-  // to the next (body velocities, U = I^A S, 1/D, u); afterwards the same storage holds the
-  // inverse mass matrix and the Minv*J^T rows of the contact problem.  Keeping these ~70 doubles
-  // out of the register file is what keeps the fp64 kernel free of scratch spills.
+  // to the next (U = I^A S, 1/D, u); afterwards the same storage holds the Cholesky factor of
+  // the inverse mass matrix and the rows of the contact problem.  Keeping these out of the
+  // register file is what keeps the fp64 kernel free of scratch spills.
   const int lane_ = threadIdx.x;
   auto L = [&](int slot) -> T& { return lds[slot * kWave + lane_]; };
-  constexpr int kW = 0, kV = 3 * NQ, kUa = 6 * NQ, kUl = 9 * NQ, kDi = 12 * NQ, kU = 13 * NQ;  // 14*NQ slots
+  constexpr int kUa = 0, kUl = 3 * NQ, kDi = 6 * NQ, kU = 7 * NQ;  // 8*NQ slots
   auto ldv = [&](int base, int i) { return mk(L(base + 3 * i), L(base + 3 * i + 1), L(base + 3 * i + 2)); };
   auto stv = [&](int base, int i, V3<T> x) { L(base + 3 * i) = x.x; L(base + 3 * i + 1) = x.y; L(base + 3 * i + 2) = x.z; };
 
   // ---- 2a. body velocities (body coordinates), outward ----
+  V3<T> wv[NQ], vv[NQ];
   {
     V3<T> w = mk<T>(0, 0, 0), v = mk<T>(0, 0, 0);
 #pragma unroll
@@ -484,8 +485,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         w = wn;
       }
       add_comp(w, md.axis(i), qd[i]);
-      stv(kW, i, w);
-      stv(kV, i, v);
+      wv[i] = w;
+      vv[i] = v;
     }
   }
 
@@ -496,7 +497,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
     for (int i = NQ - 1; i >= 0; --i) {
       const int ax = md.axis(i);
-      const V3<T> w = ldv(kW, i), v = ldv(kV, i);
+      const V3<T> w = wv[i], v = vv[i];
       // rigid-body inertia of body i about its frame origin
       const T m = par.mass(i);
       const V3<T> cm = mk(md.com(i, 0), md.com(i, 1), md.com(i, 2));
@@ -616,8 +617,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       joint_rotation<T>(md, i, sn[i], cs[i], Ri);
       const V3<T> pa_ = rtmul(Ri, aa);
       const V3<T> pl_ = rtmul(Ri, al + cross(aa, r));
-      aa = pa_ + cross(ldv(kW, i), sq);
-      al = pl_ + cross(ldv(kV, i), sq);
+      aa = pa_ + cross(wv[i], sq);
+      al = pl_ + cross(vv[i], sq);
       const T qdd = (L(kU + i) - dot(ldv(kUa, i), aa) - dot(ldv(kUl, i), al)) * L(kDi + i);
       add_comp(aa, ax, qdd);
       vs[i] = qd[i] + dt * qdd;
