@@ -131,6 +131,15 @@ class HipRuntime:
         if bool(((a < -1) | (a > 1)).any()):            # gazebo_runtime.py:67-68 warns; the task asserts
             raise AssertionError("%r invalid: actions must lie in the action space [-1, 1]" % (actions,))
         obs, rew, flags, term = sim.step(a, want_terminal=True)
+        if getattr(self.task, "host_reward", False):
+            # custom reward class (no in-kernel formula): the reference's extension point is kept
+            # through a host evaluation on the stepped (pre-reset) observation and the action
+            # history, one environment at a time -- correct but slow, meant for small batches
+            o_np = term.cpu().numpy()
+            h0 = sim.get_action_history(0).cpu().numpy()
+            h1 = sim.get_action_history(1).cpu().numpy()
+            vals = [float(self.task.calculate_reward(o_np[i], [h0[:, i], h1[:, i]])) for i in range(self.num_envs)]
+            rew = torch.as_tensor(vals, dtype=rew.dtype, device=rew.device)
         _, _, pose = sim.episode_info()
         info = BatchedInfo(done_flags=flags, terminal_observation=term, reset_orientation_id=pose,
                            truncated=(flags & abi.TRUNCATED_BIT).bool())

@@ -213,8 +213,16 @@ class MonopodTask:
         """Flatten the task into the ``Os2rTaskSpec`` fields (see include/os2r.h)."""
         if self.observation_space is None:
             self.create_spaces()
-        if getattr(self.reward, "kernel_id", None) is None:
-            raise RuntimeError(f"reward class {type(self.reward).__name__} has no in-kernel formula")
+        # A custom RewardBase subclass has no in-kernel formula: the kernel then evaluates a
+        # placeholder the task mode supports and the runtime recomputes the reward on the host
+        # from the observation and action history (slow path, see HipRuntime.step).
+        self.host_reward = getattr(self.reward, "kernel_id", None) is None
+        kernel_reward = (self.reward.kernel_id if not self.host_reward else
+                         abi.REWARD_BALANCING_V1 if "planarizer_pitch_joint_pos" in self.observation_index
+                         else abi.REWARD_STRAIGHT_V1)
+        if self.host_reward and kernel_reward == abi.REWARD_STRAIGHT_V1 and not (
+                "hip_joint_pos" in self.observation_index and "knee_joint_pos" in self.observation_index):
+            raise RuntimeError("custom reward classes need the pitch or the hip+knee positions observed")
         dof = {name: i for i, name in enumerate(model["dof_names"])}
         for jn in self.joint_names:
             if jn not in dof:
@@ -268,7 +276,7 @@ class MonopodTask:
         return {
             "obs_dim": len(kinds), "obs_kind": kinds, "obs_src": srcs, "obs_low": lows,
             "obs_high": highs, "done_lo": dlo, "done_hi": dhi,
-            "reward_id": int(self.reward.kernel_id), "normalized": 1 if self.normalized else 0,
+            "reward_id": int(kernel_reward), "normalized": 1 if self.normalized else 0,
             "idx_pitch_pos": idx.get("planarizer_pitch_joint_pos", -1),
             "idx_yaw_vel": idx.get("planarizer_yaw_joint_vel", -1),
             "idx_hip_pos": idx.get("hip_joint_pos", -1),

@@ -166,3 +166,28 @@ def test_pybind11_and_ctypes_bindings_agree(torch_mod):
     assert torch_mod.equal(a.reset(mask), b.reset(mask))
     assert b.bench_steps(2) > 0.0 and b.step_count == 14
     a.close(); b.close()
+
+
+def test_custom_reward_class_runs_on_the_host_path(torch_mod):
+    """A user-defined RewardBase subclass (reference extension point, rewards/__init__.py:9-62)."""
+    from gym_os2r_amd.rewards import RewardBase
+
+    class LowEffort(RewardBase):
+        def __init__(self, observation_index, normalized):
+            super().__init__(observation_index, normalized)
+            self.supported_task_modes = list(self._all_task_modes)
+
+        def calculate_reward(self, obs, actions):
+            return float(1.0 - 0.5 * np.abs(np.asarray(actions[0])).sum()
+                         - abs(obs[self.observation_index["planarizer_pitch_joint_pos"]]))
+
+    env = g.make("Monopod-balance-v1", num_envs=16, reward_class=LowEffort, task_mode="fixed_hip")
+    env = MonopodEnvNoRandomizer(env=lambda: env)
+    env.reset()
+    a = np.random.default_rng(0).uniform(-1, 1, (16, 2))
+    obs, rew, done, info = env.step(a)
+    term = info["terminal_observation"].cpu().numpy()
+    idx = env.unwrapped.task.observation_index["planarizer_pitch_joint_pos"]
+    want = 1.0 - 0.5 * np.abs((2.5 * a) / 2.5).sum(axis=1) - np.abs(term[:, idx])
+    np.testing.assert_allclose(rew.cpu().numpy(), want, rtol=1e-14, atol=1e-15)
+    env.close()
