@@ -310,9 +310,17 @@ __device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
 __device__ __forceinline__ double fmax_t(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float fmax_t(float a, float b) { return fmaxf(a, b); }
 
-// finite test on the bit pattern: immune to no-NaN assumptions of the optimiser
-__device__ __forceinline__ bool finite_t(double x) { return ((__double_as_longlong(x) >> 52) & 0x7ff) != 0x7ff; }
-__device__ __forceinline__ bool finite_t(float x) { return ((__float_as_int(x) >> 23) & 0xff) != 0xff; }
+// Finite test on the bit pattern of an *opaque* copy.  Under the no-NaN / no-Inf flags the optimiser
+// treats a NaN result as poison and may fold any test of it, bit tests included; the empty asm hides
+// where the value came from, so the exponent field is really inspected.
+__device__ __forceinline__ bool finite_t(double x) {
+  asm volatile("" : "+v"(x));
+  return ((__double_as_longlong(x) >> 52) & 0x7ff) != 0x7ff;
+}
+__device__ __forceinline__ bool finite_t(float x) {
+  asm volatile("" : "+v"(x));
+  return ((__float_as_int(x) >> 23) & 0xff) != 0xff;
+}
 
 // symmetric 3x3 stored as xx xy xz yy yz zz
 template <typename T> __device__ __forceinline__ V3<T> symmul(const T (&S)[6], V3<T> v) {
