@@ -885,12 +885,27 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // at mu ~ 1 (Painleve) and is kept for experiments only.
   // A row that is switched off has reciprocal rd == 0: lam = l - res*0 = l, and l already lies
   // inside its box, so the row reproduces itself without any select.
+  // The rows G are constant over the sweeps: they are fetched from LDS once, ahead of the loops.
+  // (Fetching them inside the sweep leaves every row waiting a full LDS round trip, which at
+  // one wave per SIMD nothing hides: that was half of the solver's time.)
+  T Gr[NB][3][NQ];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (!((CMASK >> b) & 1u)) continue;
+    if (wave_act[b]) {
+#pragma unroll
+      for (int row = 0; row < 3; ++row)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+          if (k <= b) Gr[b][row][k] = Gs(b, row, k);
+    }
+  }
   auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper) {
     T g[NQ];
     T r0 = -target, r1 = 0;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (k <= b) { g[k] = Gs(b, row, k); if (k & 1) r1 += g[k] * y[k]; else r0 += g[k] * y[k]; }
+      if (k <= b) { g[k] = Gr[b][row][k]; if (k & 1) r1 += g[k] * y[k]; else r0 += g[k] * y[k]; }
     const T res = r0 + r1;
     T lam = l - res * rd;
     lam = lam < lo ? lo : lam;
@@ -940,7 +955,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       if (!((CMASK >> b) & 1u)) continue;
       if (!wave_act[b]) continue;
       contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
-      const T lim = fixed_box ? limfix[b] : par.mu(b) * ln[b];
+      if (!fixed_box) limfix[b] = par.mu(b) * ln[b];   // wave-uniform: the coupled pyramid, experiments only
+      const T lim = limfix[b];
       contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true);
       contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true);
     }
