@@ -309,6 +309,8 @@ __device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
 
 __device__ __forceinline__ double fmax_t(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float fmax_t(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double fabs_t(double x) { return fabs(x); }
+__device__ __forceinline__ float fabs_t(float x) { return fabsf(x); }
 
 // Finite test on the bit pattern of an *opaque* copy.  Under the no-NaN / no-Inf flags the optimiser
 // treats a NaN result as poison and may fold any test of it, bit tests included; the empty asm hides
@@ -383,10 +385,13 @@ struct Params<T, MD, false> {
 template <typename T, typename MD>
 struct Params<T, MD, true> {
   MD m;
-  const T* ms;  // [nq][N] each
-  const T* dm;
-  const T* fr;
-  const T* mu_;
+  // global address space on purpose: generic pointers turn into flat_load, whose completions are
+  // unordered, so every wait degenerates to vmcnt(0) and also waits for requests just issued
+  using GP = const __attribute__((address_space(1))) T*;
+  GP ms;  // [nq][N] each
+  GP dm;
+  GP fr;
+  GP mu_;
   long long N, e;
   T g;
   __device__ __forceinline__ T mass(int i) const { return m.mass(i) * ms[i * N + e]; }
@@ -412,6 +417,9 @@ struct Params<T, MD, true> {
 #else
 #define OS2R_STAMP(idx) do { } while (0)
 #endif
+
+// sched_barrier mask: everything may cross except vector-memory instructions
+constexpr int kPinVmem = 0x1 | 0x2 | 0x4 | 0x8 | 0x80 | 0x100 | 0x200 | 0x400;
 
 // Opaque copy: a fresh SSA value the optimiser cannot merge with earlier uses.  Used to
 // *re*-compute cheap quantities (a joint rotation is 12 FMAs) instead of holding them in
@@ -449,6 +457,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   constexpr int NQ = MD::NQ;
   constexpr unsigned CMASK = CONTACT ? MD::CMASK : 0u;
   const T inv_dt = rcp_t(dt);
+  // the first parameter pair of the inward pass is requested before anything else
+  const T m_first = par.mass(NQ - 1), damp_first = par.damping(NQ - 1);
+  __builtin_amdgcn_sched_barrier(kPinVmem);
   // ---- 1. sin/cos of the joint angles; rotations are rebuilt from them where needed ----
   T sn[NQ], cs[NQ];
   {
@@ -502,12 +513,21 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   {
     ArtInertia<T> acc;     // children's contribution, in the current body's frame
     V3<T> pn, pf;          // children's bias force [moment; force]
+    T m_next = m_first, damp_next = damp_first;
 #pragma unroll
     for (int i = NQ - 1; i >= 0; --i) {
       const int ax = md.axis(i);
       const V3<T> w = wv[i], v = vv[i];
       // rigid-body inertia of body i about its frame origin
-      const T m = par.mass(i);
+      const T m = m_next;
+      const T damp = damp_next;
+      if (i > 0) {
+        // randomised parameters come from HBM/L2: request the next body's pair a whole body ahead
+        // (kPinVmem keeps the requests on this side; at one wave per SIMD nothing else hides them)
+        m_next = par.mass(i - 1);
+        damp_next = par.damping(i - 1);
+        __builtin_amdgcn_sched_barrier(kPinVmem);
+      }
       const V3<T> cm = mk(md.com(i, 0), md.com(i, 1), md.com(i, 2));
       const V3<T> h = m * cm;
       ArtInertia<T> I;
@@ -538,7 +558,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       const T Afull[9] = {I.A[0], I.A[1], I.A[2], I.A[1], I.A[3], I.A[4], I.A[2], I.A[4], I.A[5]};
       const V3<T> Ua = mk(Afull[ax], Afull[3 + ax], Afull[6 + ax]);
       const V3<T> Ul = mk(I.H[3 * ax], I.H[3 * ax + 1], I.H[3 * ax + 2]);
-      const T damp = par.damping(i);
       const T D = comp(Ua, ax) + dt * damp;
       const T Dinv = rcp_t(D);
       T tau = T(0);
@@ -705,6 +724,13 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   constexpr int kG = NQ * (NQ + 1) / 2;        // rows of body b at kG + 3*b*(b+1)/2 + row*(b+1) + k
   auto Lcs = [&](int i, int k) -> T& { return L(kLc + i * (i + 1) / 2 + k); };
   auto Gs = [&](int b, int row, int k) -> T& { return L(kG + 3 * b * (b + 1) / 2 + row * (b + 1) + k); };
+  T fb[NQ];   // joint friction impulse bound
+  T mub[NB];  // ground friction coefficient of the bodies that can touch
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) fb[j] = par.friction(j);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) mub[b] = ((CMASK >> b) & 1u) ? par.mu(b) : T(0);
+  __builtin_amdgcn_sched_barrier(kPinVmem);   // requested here, needed by the solver
   T y[NQ];
   T idj[NQ];  // reciprocal of Minv[j][j] = |row j of Lc|^2 (joint friction rows)
   T Lc[NQ][NQ];  // lower triangle, also mirrored to LDS for the contact-row setup
@@ -870,10 +896,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   for (int b = 0; b < NB; ++b) { ln[b] = 0; lx[b] = 0; ly[b] = 0; }
 #pragma unroll
   for (int j = 0; j < NQ; ++j) lf[j] = 0;
-  T fb[NQ];  // joint friction impulse bound
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
-    fb[j] = par.friction(j) * dt;
+    fb[j] = fb[j] * dt;
     idj[j] = fb[j] > T(0) ? idj[j] : T(0);
   }
 
@@ -948,14 +973,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   OS2R_STAMP(7);
   T limfix[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) limfix[b] = par.mu(b) * ln[b];
+  for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
   for (int it = 0; it < pgs_iters; ++it) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (!wave_act[b]) continue;
       contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
-      if (!fixed_box) limfix[b] = par.mu(b) * ln[b];   // wave-uniform: the coupled pyramid, experiments only
+      if (!fixed_box) limfix[b] = mub[b] * ln[b];   // wave-uniform: the coupled pyramid, experiments only
       const T lim = limfix[b];
       contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true);
       contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true);

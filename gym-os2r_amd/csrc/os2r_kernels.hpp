@@ -14,8 +14,6 @@ __device__ __forceinline__ double tanh_t(double x) { return tanh(x); }
 __device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
 __device__ __forceinline__ double fmod_t(double a, double b) { return fmod(a, b); }
 __device__ __forceinline__ float fmod_t(float a, float b) { return fmodf(a, b); }
-__device__ __forceinline__ double fabs_t(double x) { return fabs(x); }
-__device__ __forceinline__ float fabs_t(float x) { return fabsf(x); }
 __device__ __forceinline__ double atanh_t(double x) { return atanh(x); }
 __device__ __forceinline__ float atanh_t(float x) { return atanhf(x); }
 
@@ -249,7 +247,8 @@ __device__ __forceinline__ void bind_params(const StepArgs<T>& A, long long e, c
     // opaque base pointers: the loads below them cannot be hoisted out of the caller's loop
     const T* a = A.mass_scale; const T* b = A.damping; const T* c = A.friction; const T* d = A.mu;
     asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
-    par.ms = a; par.dm = b; par.fr = c; par.mu_ = d;
+    using GP = typename Params<T, MD, DR>::GP;
+    par.ms = (GP)a; par.dm = (GP)b; par.fr = (GP)c; par.mu_ = (GP)d;
     par.N = A.N; par.e = e;
   }
 }
