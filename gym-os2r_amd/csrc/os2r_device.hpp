@@ -25,6 +25,7 @@
 //      fixes the friction box bounds, then all rows (a convex boxed QP)
 //   7. q += dt*v  (semi-implicit Euler)
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -962,6 +963,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
   };
   const bool fixed_box = pgs_normal_iters > 0;
+  // every row fetched above has landed before the sweeps start (otherwise the waits sit inside them)
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
   for (int it = 0; it < pgs_normal_iters; ++it) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -974,18 +977,24 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   T limfix[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
-  for (int it = 0; it < pgs_iters; ++it) {
+  auto sweep = [&](auto coupled) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (!wave_act[b]) continue;
       contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
-      if (!fixed_box) limfix[b] = mub[b] * ln[b];   // wave-uniform: the coupled pyramid, experiments only
+      if (decltype(coupled)::value) limfix[b] = mub[b] * ln[b];   // the coupled pyramid, experiments only
       const T lim = limfix[b];
       contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true);
       contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true);
     }
     joint_rows();
+  };
+  if (fixed_box) {
+#pragma unroll 2
+    for (int it = 0; it < pgs_iters; ++it) sweep(std::false_type{});
+  } else {
+    for (int it = 0; it < pgs_iters; ++it) sweep(std::true_type{});
   }
   OS2R_STAMP(8);
   // back to joint velocities: v += Lc (y - y0)
