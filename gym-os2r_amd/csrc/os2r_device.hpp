@@ -446,6 +446,26 @@ __device__ __forceinline__ void joint_rotation(const MD& md, int i, T s_, T c_, 
   }
 }
 
+// next body above b that carries contact candidates (NB if none)
+template <unsigned CMASK, int NB>
+__device__ __forceinline__ constexpr int next_cand_body(int b) {
+  for (int k = b + 1; k < NB; ++k)
+    if ((CMASK >> k) & 1u) return k;
+  return NB;
+}
+// calls f(integral_constant<B>) for the candidate-carrying body B == b; false if there is none
+template <int B, int NB, unsigned CMASK, typename F>
+__device__ __forceinline__ bool for_body(int b, F&& f) {
+  if constexpr (B < NB) {
+    if constexpr ((CMASK >> B) & 1u) {
+      if (b == B) { f(std::integral_constant<int, B>{}); return true; }
+    }
+    return for_body<B + 1, NB, CMASK>(b, f);
+  } else {
+    return false;
+  }
+}
+
 template <typename T, typename MD, bool CONTACT, bool DR>
 __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& par,
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T tau_hip, T tau_knee, T dt, T erp,
@@ -977,11 +997,15 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   T limfix[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
-  auto sweep = [&](auto coupled) {
+  // The bodies in contact are nearly always a suffix of the chain (the distal links reach the
+  // ground first; a fallen robot lies on links 2..4), so the sweep exists once per suffix as
+  // straight-line code -- no per-body branch, no copies at the joins -- besides the general form.
+  auto sweep = [&](auto coupled, auto first) {
+    constexpr int kFirst = decltype(first)::value;   // < 0: general form, test every body
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
-      if (!wave_act[b]) continue;
+      if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
       contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
       if (decltype(coupled)::value) limfix[b] = mub[b] * ln[b];   // the coupled pyramid, experiments only
       const T lim = limfix[b];
@@ -990,11 +1014,21 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
     joint_rows();
   };
-  if (fixed_box) {
+  int first_act = NB;
+  bool is_suffix = true;
+#pragma unroll
+  for (int b = NB - 1; b >= 0; --b) {
+    if (!((CMASK >> b) & 1u)) continue;
+    if (wave_act[b]) { is_suffix = is_suffix && first_act == next_cand_body<CMASK, NB>(b); first_act = b; }
+  }
+  auto fixed_sweeps = [&](auto first) {
 #pragma unroll 2
-    for (int it = 0; it < pgs_iters; ++it) sweep(std::false_type{});
-  } else {
-    for (int it = 0; it < pgs_iters; ++it) sweep(std::true_type{});
+    for (int it = 0; it < pgs_iters; ++it) sweep(std::false_type{}, first);
+  };
+  if (!fixed_box) {
+    for (int it = 0; it < pgs_iters; ++it) sweep(std::true_type{}, std::integral_constant<int, -1>{});
+  } else if (!(is_suffix && first_act < NB && for_body<0, NB, CMASK>(first_act, fixed_sweeps))) {
+    fixed_sweeps(std::integral_constant<int, -1>{});
   }
   OS2R_STAMP(8);
   // back to joint velocities: v += Lc (y - y0)
