@@ -457,7 +457,8 @@ __device__ __forceinline__ constexpr int next_cand_body(int b) {
 template <int B, int NB, unsigned CMASK, typename F>
 __device__ __forceinline__ bool for_body(int b, F&& f) {
   if constexpr (B < NB) {
-    if constexpr ((CMASK >> B) & 1u) {
+    // at most three bodies per specialised form: their rows fit the register file, a fourth spills
+    if constexpr (((CMASK >> B) & 1u) && __builtin_popcount(CMASK >> B) <= 3) {
       if (b == B) { f(std::integral_constant<int, B>{}); return true; }
     }
     return for_body<B + 1, NB, CMASK>(b, f);
