@@ -405,6 +405,7 @@ struct Params<T, MD, true> {
 // Diagnostic phase stamps (separate build with -DOS2R_STAMPS, never in the shipped library):
 // shader-clock ticks per phase are summed per wave and written by lane 0 to a debug buffer that
 // nothing else reads (cdna_hip_programming.md, "In-kernel stamps").
+constexpr int kStamps = 24;   // 0..11 phases, 12.. finer marks inside the dynamics
 #ifdef OS2R_STAMPS
 #define OS2R_STAMP(idx)                                                                        \
   do {                                                                                         \
@@ -473,7 +474,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
                                         T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds,
                                         const T* __restrict__ cand_lds
 #ifdef OS2R_STAMPS
-                                        , unsigned long long (&stamps)[12], unsigned long long& stamp_prev
+                                        , unsigned long long (&stamps)[kStamps], unsigned long long& stamp_prev
 #endif
                                         ) {
   constexpr int NQ = MD::NQ;
@@ -531,6 +532,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
   }
 
+  OS2R_STAMP(12);
   // ---- 2b. articulated inertias and bias forces, inward ----
   {
     ArtInertia<T> acc;     // children's contribution, in the current body's frame
@@ -649,6 +651,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         pf = rmul(Ri, paf);
         pn = rmul(Ri, pan) + cross(r, pf);
       }
+      OS2R_STAMP(13 + (NQ - 1 - i));
     }
   }
 
@@ -707,6 +710,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       pn_[i] = di * Ua;
       pf_[i] = di * Ul;
     }
+    OS2R_STAMP(19);
     // outward: accelerations of every column, bodies 0 .. k
     V3<T> aa[NQ], al[NQ];
 #pragma unroll

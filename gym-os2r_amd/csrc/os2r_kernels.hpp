@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   }
 
 #ifdef OS2R_STAMPS
-  unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_prev = __builtin_amdgcn_s_memtime();
+  unsigned long long stamps[kStamps] = {}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
   }
 #ifdef OS2R_STAMPS
   if (A.debug && lane == 0)
-    for (int k = 0; k < 12; ++k) A.debug[blockIdx.x * 12 + k] = stamps[k];
+    for (int k = 0; k < kStamps; ++k) A.debug[blockIdx.x * kStamps + k] = stamps[k];
 #endif
   __syncthreads();
 

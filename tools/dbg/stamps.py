@@ -17,7 +17,10 @@ _lib.LIB_PATH = os.path.join(ROOT, "gym-os2r_amd", "libos2r_stamps.so")
 import bench
 
 PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y)", "contact: forward kinematics",
-          "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "-", "-"]
+          "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "-", "-",
+          "  dyn: body velocities", "  dyn: inward body 4", "  dyn: inward body 3", "  dyn: inward body 2", "  dyn: inward body 1",
+          "  dyn: inward body 0", "-", "  Minv: inward", "-", "-", "-", "-"]
+NS = 24   # kStamps in os2r_device.hpp
 
 
 def main():
@@ -29,17 +32,19 @@ def main():
     sim = HipSim(cfg)
     lib = _lib.load()
     nwg = (cfg.num_envs + 63) // 64
-    buf = torch.zeros(nwg * 12, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nwg * NS, dtype=torch.int64, device="cuda")
     lib.os2r_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
     for _ in range(50):
         sim.step(None, want_terminal=False)
     assert lib.os2r_debug_set_stamp_buffer(sim._h, C.c_void_p(buf.data_ptr())) == 0
-    acc = np.zeros(12)
+    acc = np.zeros(NS)
     for _ in range(20):
         sim.step(None, want_terminal=False)
         torch.cuda.synchronize()
-        acc += buf.cpu().numpy().reshape(nwg, 12).mean(axis=0)
+        acc += buf.cpu().numpy().reshape(nwg, NS).mean(axis=0)
     acc /= 20
+    ms = sim.bench_steps(200) / 200
+    print(f"stamp build: {ms * 1e3:.1f} us per env-step launch -> {ms * 1e6 / acc.sum():.3f} ns per tick of the stamped part")
     tot = acc.sum()
     print(f"workload {A.workload}: {tot:.0f} ticks per env-step per wave ({tot / cfg.substeps:.0f} per physics iteration)")
     for name, v in zip(PHASES, acc):
