@@ -953,11 +953,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   }
   auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper) {
     T g[NQ];
-    T r0 = -target, r1 = 0;
+    T res = -target;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (k <= b) { g[k] = Gr[b][row][k]; if (k & 1) r1 += g[k] * y[k]; else r0 += g[k] * y[k]; }
-    const T res = r0 + r1;
+      if (k <= b) { g[k] = Gr[b][row][k]; res += g[k] * y[k]; }
     T lam = l - res * rd;
     lam = lam < lo ? lo : lam;
     if (upper) lam = lam > hi ? hi : lam;
@@ -972,11 +971,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int j = 0; j < NQ; ++j) {
       // joint Coulomb friction row: J = e_j, G = row j of Lc, d = Minv[j][j]
       // (two partial sums: the sweep is a chain of dependent operations, keep it short)
-      T r0 = 0, r1 = 0;
+      T res = 0;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
-        if (k <= j) { if (k & 1) r1 += Lc[j][k] * y[k]; else r0 += Lc[j][k] * y[k]; }
-      const T res = r0 + r1;
+        if (k <= j) res += Lc[j][k] * y[k];
       T lam = lf[j] - res * idj[j];
       lam = lam < -fb[j] ? -fb[j] : lam;
       lam = lam > fb[j] ? fb[j] : lam;
