@@ -423,6 +423,9 @@ constexpr int kStamps = 24;   // 0..11 phases, 12.. finer marks inside the dynam
 // sched_barrier mask: everything may cross except vector-memory instructions
 constexpr int kPinVmem = 0x1 | 0x2 | 0x4 | 0x8 | 0x80 | 0x100 | 0x200 | 0x400;
 
+// sched_barrier mask: everything may cross except LDS instructions
+constexpr int kPinDs = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x40 | 0x400;
+
 // Opaque copy: a fresh SSA value the optimiser cannot merge with earlier uses.  Used to
 // *re*-compute cheap quantities (a joint rotation is 12 FMAs) instead of holding them in
 // registers across the whole physics iteration: fp64 state is register hungry and anything
@@ -878,6 +881,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       act[b] = W > T(0);
       wave_act[b] = __ballot(act[b]) != 0ull;
       if (wave_act[b]) {
+        // the factor rows this body needs are requested first; the Jacobian below covers the LDS trip
+        T lcb[NQ][NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            if (j <= b && k <= j) lcb[j][k] = Lcs(j, k);
+        __builtin_amdgcn_sched_barrier(kPinDs);
         const T iw = act[b] ? rcp_t(W) : T(0);
         const V3<T> pc = mk(sx * iw, sy * iw, sz * iw);
         const V3<T> pw = rmul(Rw, pc) + jo[b];
@@ -902,7 +913,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
             T gn = 0, gx = 0, gy = 0;
 #pragma unroll
             for (int j = k; j < NQ; ++j)
-              if (j <= b) { const T l = Lcs(j, k); gn += Jn[j] * l; gx += Jx[j] * l; gy += Jy[j] * l; }
+              if (j <= b) { const T l = lcb[j][k]; gn += Jn[j] * l; gx += Jx[j] * l; gy += Jy[j] * l; }
             Gs(b, 0, k) = gn; Gs(b, 1, k) = gx; Gs(b, 2, k) = gy;
             sdn += gn * gn; sdx += gx * gx; sdy += gy * gy;
           }
