@@ -88,8 +88,20 @@ def cpu_baseline(args, cfg):
             break
     dt = time.perf_counter() - t0
     orc.close()
+    # the same port on one core (SURVEY 8d asks for both), a few seconds
+    cfg1 = copy.copy(cfg)
+    cfg1.num_envs = 128
+    one = oracle_py.OracleSim(cfg1, threads=1)
+    one.step(None)
+    t1, steps1 = time.perf_counter(), 0
+    while time.perf_counter() - t1 < min(3.0, args.cpu_seconds):
+        one.step(None)
+        steps1 += 1
+    dt1 = time.perf_counter() - t1
+    one.close()
     return {"value": steps * args.cpu_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} env-steps x {args.cpu_envs} envs of the same workload, OpenMP over envs, {dt:.1f} s"}
+            "sample": f"{steps} env-steps x {args.cpu_envs} envs of the same workload, OpenMP over envs, {dt:.1f} s",
+            "single_core": {"value": steps1 * 128 / dt1, "sample": f"{steps1} env-steps x 128 envs, {dt1:.1f} s"}}
 
 
 def load_traffic():
