@@ -856,6 +856,25 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
             W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
           }
         };
+        if constexpr (MD::kStatic) {
+          // compile-time candidate counts: straight-line code, the scheduler runs the LDS reads ahead
+          // of their use and there is no loop overhead (branches, buffer copies)
+#pragma unroll
+          for (int kk = k0; kk < k1; kk += CH) {
+            T d[3 * CH];
+#pragma unroll
+            for (int j = 0; j < 3 * CH; ++j) d[j] = (kk + j / 3 < k1) ? cand_lds[3 * kk + j] : T(0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              if (kk + c < k1) {
+                const T px = d[3 * c], py = d[3 * c + 1], pz = d[3 * c + 2];
+                const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
+                const T wgt = fmax_t(margin - z, T(0));
+                W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+              }
+            }
+          }
+        } else {
         T bufA[3 * CH], bufB[3 * CH];
         int k = k0;
         const int kpair = k0 + ((k1 - k0) / (2 * CH)) * (2 * CH);   // whole pairs of chunks
@@ -875,6 +894,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
           const T wgt = fmax_t(margin - z, T(0));
           W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+        }
         }
       }
       OS2R_STAMP(5);

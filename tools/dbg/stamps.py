@@ -34,19 +34,22 @@ def main():
     nwg = (cfg.num_envs + 63) // 64
     buf = torch.zeros(nwg * NS, dtype=torch.int64, device="cuda")
     lib.os2r_debug_set_stamp_buffer.argtypes = [C.c_void_p, C.c_void_p]
-    for _ in range(50):
-        sim.step(None, want_terminal=False)
+    sim.bench_steps(int(sys.argv[2]) if len(sys.argv) > 2 else 50)
     assert lib.os2r_debug_set_stamp_buffer(sim._h, C.c_void_p(buf.data_ptr())) == 0
     acc = np.zeros(NS)
     for _ in range(20):
         sim.step(None, want_terminal=False)
         torch.cuda.synchronize()
-        acc += buf.cpu().numpy().reshape(nwg, NS).mean(axis=0)
+        per_wave = buf.cpu().numpy().reshape(nwg, NS)
+        acc += per_wave.mean(axis=0)
+        tot_w = per_wave.sum(axis=1)
+        spread = (tot_w.min(), tot_w.mean(), tot_w.max())
     acc /= 20
     ms = sim.bench_steps(200) / 200
     print(f"stamp build: {ms * 1e3:.1f} us per env-step launch -> {ms * 1e6 / acc.sum():.3f} ns per tick of the stamped part")
     tot = acc.sum()
     print(f"workload {A.workload}: {tot:.0f} ticks per env-step per wave ({tot / cfg.substeps:.0f} per physics iteration)")
+    print(f"per-wave ticks of the last step: min {spread[0]:.0f} mean {spread[1]:.0f} max {spread[2]:.0f} (max/mean {spread[2] / spread[1]:.3f})")
     for name, v in zip(PHASES, acc):
         print(f"  {name:42s} {v / cfg.substeps:9.0f} ticks/iter  {100 * v / tot:5.1f} %")
 
