@@ -857,6 +857,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           }
         };
         if constexpr (MD::kStatic) {
+          const T mo = margin - ow[2];
           // compile-time candidate counts: straight-line code, the scheduler runs the LDS reads ahead
           // of their use and there is no loop overhead (branches, buffer copies)
 #pragma unroll
@@ -868,8 +869,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
             for (int c = 0; c < CH; ++c) {
               if (kk + c < k1) {
                 const T px = d[3 * c], py = d[3 * c + 1], pz = d[3 * c + 2];
-                const T z = Rw[6] * px + Rw[7] * py + Rw[8] * pz + ow[2];
-                const T wgt = fmax_t(margin - z, T(0));
+                // margin - z with the frame origin folded into the constant term: one add less
+                const T mz = __builtin_fma(-Rw[6], px, __builtin_fma(-Rw[7], py, __builtin_fma(-Rw[8], pz, mo)));
+                const T wgt = fmax_t(mz, T(0));
                 W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
               }
             }
