@@ -154,7 +154,8 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("OS2R_BENCH_FORCE_DIST") == "1"   # the latter: rehearse RCCL init on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -166,7 +167,7 @@ def main():
     esz = 8 if args.dtype == "f64" else 4
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +177,7 @@ def main():
     kernel_ms = sim.bench_steps(args.steps)           # K launches, HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
@@ -220,7 +221,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)
     sim.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
