@@ -39,6 +39,7 @@ struct SimBase {
   int32_t* steps = nullptr;
   uint32_t* episode = nullptr;
   uint8_t* pose = nullptr;
+  unsigned int* violations = nullptr;
   // scratch outputs for os2r_bench_steps
   void *b_obs = nullptr, *b_rew = nullptr;
   uint8_t* b_done = nullptr;
@@ -186,7 +187,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.q = (T*)s->q; a.qd = (T*)s->qd; a.hist = (T*)s->hist;
   a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
-  a.steps = s->steps; a.episode = s->episode; a.pose = s->pose;
+  a.steps = s->steps; a.episode = s->episode; a.pose = s->pose; a.violations = s->violations;
   a.debug = s->debug;
   return a;
 }
@@ -307,6 +308,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   if ((rc = dev_alloc(s, (void**)&s->steps, N * 4))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->episode, N * 4))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->pose, N))) return fail(rc);
+  if ((rc = dev_alloc(s, (void**)&s->violations, 4))) return fail(rc);
   if ((rc = dev_alloc(s, &s->b_obs, (size_t)s->D * N * e))) return fail(rc);
   if ((rc = dev_alloc(s, &s->b_rew, N * e))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->b_done, N))) return fail(rc);
@@ -409,6 +411,13 @@ int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_de
   if (steps_dev) HIP_TRY(sim, hipMemcpyAsync(steps_dev, sim->steps, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (episode_dev) HIP_TRY(sim, hipMemcpyAsync(episode_dev, sim->episode, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (pose_dev) HIP_TRY(sim, hipMemcpyAsync(pose_dev, sim->pose, N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void* stream) {
+  if (!sim || !dst) return OS2R_ERR_INVALID;
+  HIP_TRY(sim, hipMemcpyAsync(dst, sim->violations, 4, hipMemcpyDefault, (hipStream_t)stream));
+  if (clear) HIP_TRY(sim, hipMemsetAsync(sim->violations, 0, 4, (hipStream_t)stream));
   return OS2R_OK;
 }
 

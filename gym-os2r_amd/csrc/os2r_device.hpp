@@ -121,6 +121,7 @@ struct StepArgs {
   int32_t* __restrict__ steps;
   uint32_t* __restrict__ episode;
   uint8_t* __restrict__ pose;
+  unsigned int* __restrict__ violations;  // count of out-of-range caller actions (nullable)
   // step I/O
   const T* __restrict__ actions;  // [N][2] or null
   T* __restrict__ obs;            // [N][D] or null

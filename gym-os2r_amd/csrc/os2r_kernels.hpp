@@ -336,6 +336,8 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(sizeof(T)
   if (A.actions) {
     ax = A.actions[2 * e];
     ay = A.actions[2 * e + 1];
+    const bool outside = ax < T(-1) || ax > T(1) || ay < T(-1) || ay > T(1);
+    if (__ballot(outside) != 0ull && outside && A.violations) atomicAdd(A.violations, 1u);
   } else {
     double u0, u1;
     uniform2(A.seed, (uint32_t)(A.env_offset + e), kStreamAction, (uint32_t)A.step_count,

@@ -25,7 +25,28 @@ from ..config import SettingsConfig
 
 class BatchedInfo(dict):
     """Info of one batched step.  Dict of tensors; ``as_list()`` builds the per-env list of dicts
-    a SubprocVecEnv consumer expects (use for small N only)."""
+    a SubprocVecEnv consumer expects (use for small N only).  Derived entries (``truncated``,
+    ``reset_orientation_id``) are produced on first access: a training loop that never looks at
+    them does not pay their kernel launches every step.  Read them before the next ``step()``."""
+
+    def __init__(self, *args, lazy=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._lazy = dict(lazy or {})
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            self[key] = self._lazy.pop(key)()
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._lazy)
 
     def as_list(self, pose_names):
         n = int(self["done_flags"].shape[0])
@@ -71,6 +92,7 @@ class HipRuntime:
         self._reset_mode = abi.RESET_FIXED
         self._randomize_params = False
         self._sim = None
+        self._bad_flag, self._bad_event, self._bad_pending, self._bad_slot = None, None, [False, False], 0
         cfg = getattr(self.task, "cfg", None) or SettingsConfig()
         self.model = dict(get_model(cfg.get_config(f"task_modes/{self.task.task_mode}/model")))
         self.pose_names = list(cfg.get_config("/resets").keys())
@@ -113,6 +135,7 @@ class HipRuntime:
 
     def reset(self, mask=None):
         """Reset every environment (or those in ``mask``) and return the observations [N, D]."""
+        self._raise_if_bad_actions(drain=True)
         first = self._sim is None
         sim = self.sim
         if first and mask is None:
@@ -125,12 +148,31 @@ class HipRuntime:
         """actions [N, 2] in [-1, 1] -> (obs [N, D], reward [N], done [N] bool, BatchedInfo)."""
         import torch
         sim = self.sim
+        # The action space is enforced (gazebo_runtime.py:67-68 warns; the task asserts).  Host actions
+        # are checked on the host before the upload.  Device actions are checked by the kernel and the
+        # verdict is read two calls later (or in reset()/close()): reading it earlier would make the
+        # host wait for a kernel that is still running, every step.
+        self._raise_if_bad_actions()
+        if not isinstance(actions, torch.Tensor) or not actions.is_cuda:
+            a_host = np.asarray(actions, dtype=np.float64)
+            if ((a_host < -1) | (a_host > 1)).any():
+                raise AssertionError("%r invalid: actions must lie in the action space [-1, 1]" % (actions,))
         a = torch.as_tensor(actions, device=sim.device).to(sim.dtype)
         if a.dim() == 1 and self.num_envs == 1:
             a = a.reshape(1, 2)
-        if bool(((a < -1) | (a > 1)).any()):            # gazebo_runtime.py:67-68 warns; the task asserts
-            raise AssertionError("%r invalid: actions must lie in the action space [-1, 1]" % (actions,))
+        device_actions = isinstance(actions, torch.Tensor) and actions.is_cuda
         obs, rew, flags, term = sim.step(a, want_terminal=True)
+        if device_actions:
+            # the kernel clamps out-of-range actions and counts them; the count travels to pinned
+            # host memory behind this step and is looked at in the next call
+            if self._bad_flag is None:
+                self._bad_flag = torch.zeros(2, dtype=torch.int32).pin_memory()
+                self._bad_event = [torch.cuda.Event(), torch.cuda.Event()]
+            k = self._bad_slot
+            sim.action_violations_into(self._bad_flag[k:k + 1], clear=True)
+            self._bad_event[k].record(torch.cuda.current_stream(sim.device))
+            self._bad_pending[k] = True
+            self._bad_slot = 1 - k
         if getattr(self.task, "host_reward", False):
             # custom reward class (no in-kernel formula): the reference's extension point is kept
             # through a host evaluation on the stepped (pre-reset) observation and the action
@@ -140,10 +182,22 @@ class HipRuntime:
             h1 = sim.get_action_history(1).cpu().numpy()
             vals = [float(self.task.calculate_reward(o_np[i], [h0[:, i], h1[:, i]])) for i in range(self.num_envs)]
             rew = torch.as_tensor(vals, dtype=rew.dtype, device=rew.device)
-        _, _, pose = sim.episode_info()
-        info = BatchedInfo(done_flags=flags, terminal_observation=term, reset_orientation_id=pose,
-                           truncated=(flags & abi.TRUNCATED_BIT).bool())
+        info = BatchedInfo(done_flags=flags, terminal_observation=term,
+                           lazy={"reset_orientation_id": lambda: sim.episode_info()[2],
+                                 "truncated": lambda: (flags & abi.TRUNCATED_BIT).bool()})
         return obs, rew, flags != 0, info
+
+    def _raise_if_bad_actions(self, drain: bool = False):
+        """Look at the verdicts that are due: the one of two calls ago (its kernel has finished while the
+        last one runs, so nothing waits), or all of them when draining in reset()/close()."""
+        for k in ((0, 1) if drain else (self._bad_slot,)):
+            if self._bad_pending[k]:
+                self._bad_event[k].synchronize()
+                self._bad_pending[k] = False
+                if int(self._bad_flag[k]) != 0:
+                    self._bad_pending = [False, False]
+                    raise AssertionError("invalid: actions of an earlier step() left the action space [-1, 1] "
+                                         "(they were clamped, as the backend clamps the torque)")
 
     def get_state_info(self, obs, actions):
         """(reward, done) recomputed on the host for one observation (tasks/monopod.py:348-366)."""
@@ -153,9 +207,12 @@ class HipRuntime:
         return None                                      # headless: there is no Gazebo GUI to open
 
     def close(self):
-        if self._sim is not None:
-            self._sim.close()
-            self._sim = None
+        try:
+            self._raise_if_bad_actions(drain=True)
+        finally:
+            if self._sim is not None:
+                self._sim.close()
+                self._sim = None
 
     @property
     def unwrapped(self):

@@ -69,6 +69,9 @@ class _PybindLib:
     def os2r_get_episode_info(self, h, s, e, p, st):
         return self.m.get_episode_info(self._a(h), self._a(s), self._a(e), self._a(p), self._a(st))
 
+    def os2r_get_action_violations(self, h, d, clear, st):
+        return self.m.get_action_violations(self._a(h), self._a(d), int(clear), self._a(st))
+
     def os2r_get_step_count(self, h, out_ref):
         rc, v = self.m.get_step_count(self._a(h))
         out_ref._obj.value = v
@@ -209,6 +212,12 @@ class HipSim:
         self._check(self._lib.os2r_get_episode_info(self._h, _ptr(steps), _ptr(epi), _ptr(pose), self._stream()),
                     "os2r_get_episode_info")
         return steps, epi, pose
+
+    def action_violations_into(self, dst: torch.Tensor, clear: bool = True):
+        """Copy the running count of out-of-range caller actions into ``dst`` (one int32/uint32 element,
+        device or pinned host memory) on the current stream; nothing waits."""
+        self._check(self._lib.os2r_get_action_violations(self._h, C.c_void_p(dst.data_ptr()), 1 if clear else 0,
+                                                        self._stream()), "os2r_get_action_violations")
 
     @property
     def step_count(self) -> int:

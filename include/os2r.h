@@ -201,6 +201,13 @@ int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* strea
 int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev,
               uint8_t* done_dev, void* term_obs_dev, void* stream);
 
+/* Caller-provided actions outside [-1, 1]: the reference asserts on them in Python
+ * (tasks/monopod.py:222, runtimes/gazebo_runtime.py:67-68) and its backend clamps the torque
+ * (tasks/monopod.py:313-316).  The kernel clamps and counts them; this copies the running count
+ * of offending environments to dst (device or pinned host memory, ordered on the stream, so a
+ * host binding can look at it one call later without stalling) and clears it if `clear`.   */
+int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void* stream);
+
 /* State access in chain dof order, SoA [nq][num_envs], handle's dtype. */
 int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream);
 int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* stream);

@@ -191,3 +191,34 @@ def test_custom_reward_class_runs_on_the_host_path(torch_mod):
     want = 1.0 - 0.5 * np.abs((2.5 * a) / 2.5).sum(axis=1) - np.abs(term[:, idx])
     np.testing.assert_allclose(rew.cpu().numpy(), want, rtol=1e-14, atol=1e-15)
     env.close()
+
+
+@pytest.mark.gpu
+def test_device_actions_are_validated_without_stalling(torch_mod):
+    """Device action tensors are range-checked by the kernel (clamped + counted); the verdict surfaces
+    two calls later (or in reset()/close()), host arrays are rejected immediately."""
+    env = g.make("Monopod-balance-v1", num_envs=256, seed=1)
+    env.reset()
+    good = torch_mod.zeros(256, 2, dtype=torch_mod.float64, device="cuda")
+    bad = good.clone(); bad[17, 1] = 1.25
+    env.step(good); env.step(good)
+    env.step(bad)                                   # accepted (clamped) now ...
+    env.step(good)
+    with pytest.raises(AssertionError, match="earlier step"):
+        env.step(good)                              # ... reported here
+    env.step(good); env.step(good); env.step(good)  # the count was cleared
+    env.step(bad)
+    with pytest.raises(AssertionError, match="earlier step"):
+        env.reset()
+    with pytest.raises(AssertionError, match="invalid"):
+        env.step(np.full((256, 2), -1.5))           # host data: immediate
+    # the clamp itself: +1.25 acts like +1.0
+    e1, e2 = (g.make("Monopod-balance-v1", num_envs=64, seed=3) for _ in range(2))
+    e1.reset(); e2.reset()
+    a1 = torch_mod.full((64, 2), 1.25, dtype=torch_mod.float64, device="cuda")
+    o1 = e1.step(a1)[0]
+    o2 = e2.step(torch_mod.ones_like(a1))[0]
+    assert torch_mod.equal(o1, o2)
+    with pytest.raises(AssertionError):
+        e1.close()
+    e2.close(); env.close()
