@@ -37,6 +37,9 @@ WORKLOADS = {
     "C3": ("free_hip", "BalancingV1", True, False, "65536 envs free_hip balancing with ground contact"),
     "C4": ("free_hip", "BalancingV1", True, True,
            "65536 envs/GPU free_hip balancing, ground contact, per-env domain randomisation (C5 = 8 x C4)"),
+    # not a BASELINE configuration: the reference's default env id (Monopod-balance-v1) at the same batch size
+    "V1": ("fixed_hip_simple", "BalancingV1", True, True,
+           "65536 envs/GPU Monopod-balance-v1 (fixed_hip_simple, 4 dof), ground contact, domain randomisation"),
 }
 
 
