@@ -51,6 +51,10 @@ def build_config(args, rank, world):
     task = MonopodTask(1000, task_mode=mode, reward_class=getattr(rewards, reward), reset_positions=["stand"])
     task.create_spaces()
     model = g.get_model(g.config.SettingsConfig().get_config(f"task_modes/{mode}/model"))
+    if getattr(args, "runtime_model", False):
+        # any change to the robot constants leaves the four compiled-in variants: run-time-model kernels
+        model = dict(model)
+        model["mass"] = [m * (1.0 + 1e-9) for m in model["mass"]]
     spec = task.kernel_spec(model, reset_mode=abi.RESET_RANDOM if dr else abi.RESET_FIXED,
                             randomize_params=dr, max_episode_steps=100_000)
     n = args.envs_per_gpu
@@ -130,6 +134,8 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--runtime-model", action="store_true",
+                    help="perturb the robot constants so that the generic (run-time model) kernels are used")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-time reduction (nccl = RCCL; gloo lets several "
                          "ranks share one GPU when rehearsing the multi-rank path)")
