@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -16,7 +18,28 @@
 
 using namespace os2r;
 
-namespace os2r { int static_model_id(const Os2rModel& m); }
+namespace os2r {
+int static_model_id(const Os2rModel& m);
+bool same_model(const Os2rModel& a, const Os2rModel& b);
+}
+
+// model-specialised code objects registered by the host binding (include/os2r.h)
+struct JitEntry {
+  Os2rModel model;
+  int dtype = 0, device = 0;
+  hipModule_t module = nullptr;
+  hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [contact][per-env parameters]
+};
+
+static std::mutex g_jit_mutex;
+static std::deque<JitEntry> g_jit;   // entries are never removed: handles keep pointers into it
+
+static const JitEntry* find_jit(const Os2rModel& m, int dtype, int device) {
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  for (auto it = g_jit.rbegin(); it != g_jit.rend(); ++it)
+    if (it->dtype == dtype && it->device == device && os2r::same_model(it->model, m)) return &*it;
+  return nullptr;
+}
 
 namespace {
 
@@ -28,6 +51,7 @@ struct SimBase {
   int nq = 0, D = 0;
   unsigned cmask = 0;
   int model_id = -1;  // matching constexpr model table, -1: run-time model kernels
+  const JitEntry* jit = nullptr;  // registered model-specialised code object (os2r_register_model_kernels)
   bool dr = false;
   size_t esz = 8;
   unsigned long long step_count = 0;
@@ -206,7 +230,15 @@ template <typename T>
 int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* done, void* term, hipStream_t st) {
   StepArgs<T> a = make_args<T>(s);
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
-  if (Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
+  const bool contact = s->cfg.contact != 0 && s->cmask != 0u;
+  if (s->jit && s->jit->fn[contact][s->dr]) {
+    // the robot's own code object: same StepArgs, passed as the kernel-argument buffer
+    StepArgs<T> args = a;
+    size_t size = sizeof(args);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    const unsigned grid = (unsigned)((a.N + kWave - 1) / kWave);
+    HIP_TRY(s, hipModuleLaunchKernel(s->jit->fn[contact][s->dr], grid, 1, 1, kWave, 1, 1, 0, st, nullptr, extra));
+  } else if (Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
   HIP_TRY(s, hipGetLastError());
   s->step_count += 1;
   return OS2R_OK;
@@ -290,6 +322,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   // the randomising reset mode, or a later os2r_set_params (which flips this on)
   s->dr = cfg->task.reset_mode == OS2R_RESET_RANDOM;
   s->model_id = static_model_id(cfg->model);
+  if (s->model_id < 0) s->jit = find_jit(cfg->model, cfg->dtype, cfg->device);
   s->cmask = 0;
   if (cfg->contact)
     for (int k = 0; k < cfg->model.ncand; ++k) s->cmask |= 1u << cfg->model.cand_body[k];
@@ -411,6 +444,30 @@ int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_de
   if (steps_dev) HIP_TRY(sim, hipMemcpyAsync(steps_dev, sim->steps, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (episode_dev) HIP_TRY(sim, hipMemcpyAsync(episode_dev, sim->episode, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (pose_dev) HIP_TRY(sim, hipMemcpyAsync(pose_dev, sim->pose, N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_model_is_compiled_in(const Os2rModel* model) {
+  return model && os2r::static_model_id(*model) >= 0 ? 1 : 0;
+}
+
+int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t device, const char* path) {
+  if (!model || !path || (dtype != OS2R_F32 && dtype != OS2R_F64)) { g_create_error = "os2r_register_model_kernels: bad argument"; return OS2R_ERR_INVALID; }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "os2r_register_model_kernels: hipSetDevice failed"; return OS2R_ERR_HIP; }
+  JitEntry e;
+  e.model = *model; e.dtype = dtype; e.device = device;
+  hipError_t rc = hipModuleLoad(&e.module, path);
+  if (rc != hipSuccess) { g_create_error = std::string("hipModuleLoad(") + path + "): " + hipGetErrorString(rc); return OS2R_ERR_HIP; }
+  int found = 0;
+  for (int c = 0; c < 2; ++c)
+    for (int d = 0; d < 2; ++d) {
+      const std::string name = std::string("os2r_jit_step_c") + char('0' + c) + "_d" + char('0' + d);
+      if (hipModuleGetFunction(&e.fn[c][d], e.module, name.c_str()) == hipSuccess) ++found; else e.fn[c][d] = nullptr;
+    }
+  (void)hipGetLastError();   // a missing variant is not an error
+  if (!found) { (void)hipModuleUnload(e.module); g_create_error = std::string(path) + " exports no os2r_jit_step_* kernel"; return OS2R_ERR_INVALID; }
+  std::lock_guard<std::mutex> lock(g_jit_mutex);
+  g_jit.push_back(e);
   return OS2R_OK;
 }
 

@@ -302,10 +302,10 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
   else return MD{as_const(A.model)};
 }
 
+// One env-step of this wave's 64 environments: the body of every step kernel (the templated ones below and
+// the model-specialised ones of os2r_jit_unit.hip).
 template <typename T, typename MD, bool CONTACT, bool DR>
-// fp32 state fits two waves per SIMD (<= 256 registers, 17.7 KB LDS): the second wave hides what a lone
-// wave pays for in full (branches, LDS hand-overs); +28 % at 131 072 envs per GPU.  fp64 needs ~450 registers.
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 2 : 1))) void step_kernel(const StepArgs<T> A) {
+__device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
   __shared__ T tile[lds_words<NQ>() + (CONTACT && MD::CMASK != 0u ? kCandWords : 0)];
   const int lane = threadIdx.x;
@@ -423,6 +423,16 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(sizeof(T)
     if (A.reward) A.reward[e] = rew;
     if (A.done) A.done[e] = flag;
   }
+}
+
+// fp32 state fits two waves per SIMD (<= 256 registers, 17.7 KB LDS): the second wave hides what a lone
+// wave pays for in full (branches, LDS hand-overs); +28 % at 131 072 envs per GPU.  fp64 needs ~450 registers.
+#define OS2R_STEP_KERNEL_ATTRS(REAL) \
+  __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
+
+template <typename T, typename MD, bool CONTACT, bool DR>
+__global__ OS2R_STEP_KERNEL_ATTRS(T) void step_kernel(const StepArgs<T> A) {
+  step_body<T, MD, CONTACT, DR>(A);
 }
 
 // ----------------------------------------------------------------------------------------

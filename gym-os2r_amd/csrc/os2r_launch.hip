@@ -84,6 +84,25 @@ static bool matches(const Os2rModel& m) {
   return true;
 }
 
+// bit-for-bit equality of two robots (gravity excluded, padding ignored)
+bool same_model(const Os2rModel& a, const Os2rModel& b) {
+  if (a.nq != b.nq || a.ncand != b.ncand) return false;
+  for (int i = 0; i < a.nq; ++i) {
+    if (a.axis[i] != b.axis[i] || a.mass[i] != b.mass[i] || a.damping[i] != b.damping[i] ||
+        a.friction[i] != b.friction[i] || a.mu[i] != b.mu[i] || a.cand_radius[i] != b.cand_radius[i]) return false;
+    for (int k = 0; k < 9; ++k) if (a.rfix[i][k] != b.rfix[i][k]) return false;
+    for (int k = 0; k < 3; ++k)
+      if (a.rpos[i][k] != b.rpos[i][k] || a.com[i][k] != b.com[i][k] || a.cand_center[i][k] != b.cand_center[i][k]) return false;
+    for (int k = 0; k < 6; ++k) if (a.icom[i][k] != b.icom[i][k]) return false;
+  }
+  for (int k = 0; k < 2; ++k) if (a.act_dof[k] != b.act_dof[k] || a.max_torque[k] != b.max_torque[k]) return false;
+  for (int c = 0; c < a.ncand; ++c) {
+    if (a.cand_body[c] != b.cand_body[c]) return false;
+    for (int j = 0; j < 3; ++j) if (a.cand_p[c][j] != b.cand_p[c][j]) return false;
+  }
+  return true;
+}
+
 int static_model_id(const Os2rModel& m) {
   if (matches<0>(m)) return 0;
   if (matches<1>(m)) return 1;

@@ -47,5 +47,8 @@ PYBIND11_MODULE(_os2r_py, m) {
     { py::gil_scoped_release rel; rc = os2r_bench_steps(H(h), n, P(st), &ms); }
     return py::make_tuple(rc, ms);
   });
+  m.def("model_is_compiled_in", [](addr model) { return os2r_model_is_compiled_in((const Os2rModel*)P(model)); });
+  m.def("register_model_kernels", [](addr model, int dtype, int device, const std::string& path) {
+    return os2r_register_model_kernels((const Os2rModel*)P(model), dtype, device, path.c_str()); });
   m.def("last_error", [](addr h) { return std::string(os2r_last_error(H(h))); });
 }

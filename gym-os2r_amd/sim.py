@@ -110,6 +110,9 @@ class HipSim:
         self.cfg = cfg
         self.N, self.nq, self.D = int(cfg.num_envs), int(cfg.model.nq), int(cfg.task.obs_dim)
         self.dtype = torch.float64 if cfg.dtype == abi.F64 else torch.float32
+        # a robot that is not compiled in gets its own kernels (gym_os2r_amd/jit.py; OS2R_JIT=0: generic ones)
+        from . import jit
+        self.specialised = jit.specialise(_lib.load(), cfg)
         self._h = C.c_void_p()
         rc = self._lib.os2r_create(C.byref(cfg), C.byref(self._h))
         if rc != abi.OK:

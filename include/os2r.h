@@ -201,6 +201,19 @@ int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* strea
 int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev,
               uint8_t* done_dev, void* term_obs_dev, void* stream);
 
+/* Model-specialised kernels.  A robot that is not one of the four compiled-in reference variants
+ * runs on generic kernels that read its constants through scalar loads (about half the speed).
+ * A host binding may instead compile the step kernels for that robot -- gym_os2r_amd/jit.py does:
+ * it writes the robot's constants as a constexpr table and runs `hipcc --genco` on
+ * gym-os2r_amd/csrc/os2r_jit_unit.hip -- and register the code object here.  os2r_create then
+ * uses it for every handle on `device` whose dtype matches and whose Os2rModel equals `model`
+ * bit for bit (gravity_z excluded: it is a per-handle value).  Variants the code object does not
+ * export (os2r_jit_step_c{0,1}_d{0,1}: contact off/on, per-env parameters off/on) fall back to the
+ * generic kernels.  Errors: os2r_last_error(NULL).                                          */
+int os2r_model_is_compiled_in(const Os2rModel* model);
+int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t device,
+                                const char* code_object_path);
+
 /* Caller-provided actions outside [-1, 1]: the reference asserts on them in Python
  * (tasks/monopod.py:222, runtimes/gazebo_runtime.py:67-68) and its backend clamps the torque
  * (tasks/monopod.py:313-316).  The kernel clamps and counts them; this copies the running count

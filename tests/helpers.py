@@ -33,3 +33,16 @@ def make_config(mode="fixed_hip", reward_name="BalancingV1", normalized=True,
     spec = task.kernel_spec(model, reset_mode=reset_mode, randomize_params=randomize_params,
                             max_episode_steps=max_episode_steps)
     return abi.config_struct(model, spec, **cfg_kw), task, model
+
+
+def perturbed_model(mode, rng):
+    """The reference's chain with every inertial / frame number nudged: no compiled-in table matches."""
+    m = {k: (list(v) if isinstance(v, list) else v) for k, v in model_for(mode).items()}
+    nq = m["nq"]
+    m["mass"] = [x * rng.uniform(0.9, 1.1) for x in m["mass"]]
+    m["com"] = [[c + rng.uniform(-2e-3, 2e-3) for c in row] for row in m["com"]]
+    m["rpos"] = [[c + rng.uniform(-1e-3, 1e-3) for c in row] for row in m["rpos"]]
+    m["damping"] = [0.01 * rng.uniform(0.5, 1.5) for _ in range(nq)]
+    m["friction"] = [0.004 * rng.uniform(0.5, 1.5) for _ in range(nq)]
+    m["mu"] = [rng.uniform(0.3, 1.0) for _ in range(nq)]
+    return m

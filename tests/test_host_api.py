@@ -247,3 +247,29 @@ def test_pybind11_module_mirrors_the_c_abi():
         assert hasattr(m, sym[len("os2r_"):]), sym
     rc, handle = m.create(0)                       # null config: rejected, no device touched
     assert rc == abi.ERR_INVALID and handle == 0 and "null config" in m.last_error(0)
+
+
+def test_jit_builds_a_code_object_for_a_custom_robot(monkeypatch):
+    """gym_os2r_amd/jit.py: the robot's constexpr table and the hipcc --genco build (cross-compiles without a
+    GPU).  The code object must export the two kernels of the requested contact flag; a second request is a
+    cache hit.  (Loading and running it is a GPU test.)"""
+    from conftest import KERNEL_CACHE
+    from helpers import perturbed_model
+    from gym_os2r_amd import jit
+    if jit.hipcc_path() is None:
+        pytest.skip("no hipcc on this machine")
+    monkeypatch.setenv("OS2R_KERNEL_CACHE", KERNEL_CACHE)
+    model = perturbed_model("free_hip", np.random.default_rng(77))
+    ms = abi.model_struct(model)
+    src = jit.table_source(ms)
+    assert "struct Tables<100>" in src and f"static constexpr int nq = {model['nq']};" in src
+    assert float(model["mass"][2]).hex() in src                      # exact hex-float literals
+    path = jit.build(ms, abi.F64, True)
+    assert os.path.getsize(path) > 100_000
+    blob = open(path, "rb").read()
+    assert b"os2r_jit_step_c1_d0" in blob and b"os2r_jit_step_c1_d1" in blob and b"os2r_jit_step_c0_d0" not in blob
+    mtime = os.path.getmtime(path)
+    assert jit.build(ms, abi.F64, True) == path and os.path.getmtime(path) == mtime
+    assert jit.code_object_path(ms, abi.F32, True) != path and jit.code_object_path(ms, abi.F64, False) != path
+    ms.mass[0] = np.nextafter(ms.mass[0], 1.0)
+    assert jit.code_object_path(ms, abi.F64, True) != path           # any constant of the robot is part of the key
