@@ -505,7 +505,7 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) 
 }
 
 #ifdef OS2R_STAMPS
-// diagnostic builds only (libos2r_stamps.so): per-wave phase stamps, 8 x uint64 per workgroup
+// diagnostic builds only (libos2r_stamps.so): per-wave phase stamps, kStamps x uint64 per workgroup
 int os2r_debug_set_stamp_buffer(Os2rSim* sim, unsigned long long* buf_dev) {
   if (!sim) return OS2R_ERR_INVALID;
   sim->debug = buf_dev;
