@@ -28,7 +28,7 @@ struct JitEntry {
   Os2rModel model;
   int dtype = 0, device = 0;
   hipModule_t module = nullptr;
-  hipFunction_t fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [contact][per-env parameters]
+  hipFunction_t fn[2][2][2] = {};   // [contact][per-env parameters][default sweep counts compiled in]
 };
 
 static std::mutex g_jit_mutex;
@@ -231,13 +231,16 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
   StepArgs<T> a = make_args<T>(s);
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
   const bool contact = s->cfg.contact != 0 && s->cmask != 0u;
-  if (s->jit && s->jit->fn[contact][s->dr]) {
+  const bool std_sweeps = s->cfg.pgs_iters == kStdPgsIters && s->cfg.pgs_normal_iters == kStdPgsNormalIters;
+  const hipFunction_t jit_fn = !s->jit ? nullptr
+      : (std_sweeps && s->jit->fn[contact][s->dr][1]) ? s->jit->fn[contact][s->dr][1] : s->jit->fn[contact][s->dr][0];
+  if (jit_fn) {
     // the robot's own code object: same StepArgs, passed as the kernel-argument buffer
     StepArgs<T> args = a;
     size_t size = sizeof(args);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     const unsigned grid = (unsigned)((a.N + kWave - 1) / kWave);
-    HIP_TRY(s, hipModuleLaunchKernel(s->jit->fn[contact][s->dr], grid, 1, 1, kWave, 1, 1, 0, st, nullptr, extra));
+    HIP_TRY(s, hipModuleLaunchKernel(jit_fn, grid, 1, 1, kWave, 1, 1, 0, st, nullptr, extra));
   } else if (Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
   HIP_TRY(s, hipGetLastError());
   s->step_count += 1;
@@ -462,7 +465,9 @@ int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t d
   for (int c = 0; c < 2; ++c)
     for (int d = 0; d < 2; ++d) {
       const std::string name = std::string("os2r_jit_step_c") + char('0' + c) + "_d" + char('0' + d);
-      if (hipModuleGetFunction(&e.fn[c][d], e.module, name.c_str()) == hipSuccess) ++found; else e.fn[c][d] = nullptr;
+      for (int v = 0; v < 2; ++v)
+        if (hipModuleGetFunction(&e.fn[c][d][v], e.module, (name + (v ? "_s" : "")).c_str()) == hipSuccess) ++found;
+        else e.fn[c][d][v] = nullptr;
     }
   (void)hipGetLastError();   // a missing variant is not an error
   if (!found) { (void)hipModuleUnload(e.module); g_create_error = std::string(path) + " exports no os2r_jit_step_* kernel"; return OS2R_ERR_INVALID; }

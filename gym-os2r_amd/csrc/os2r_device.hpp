@@ -35,6 +35,8 @@
 namespace os2r {
 
 constexpr int kWave = 64;
+// the sweep counts of the default configuration: kernels built for them have compile-time loop bounds (+2 %)
+constexpr int kStdPgsIters = 20, kStdPgsNormalIters = 3;
 
 // ----------------------------------------------------------------------------------------
 // uniform (per-handle) device data

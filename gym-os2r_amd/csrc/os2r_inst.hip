@@ -21,7 +21,11 @@ using T = OS2R_REAL;
 template <typename MD, bool CONTACT, bool DR>
 static void launch_step(const StepArgs<T>& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave)), block(kWave);
-  hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR>), grid, block, 0, s, a);
+  // the compiled-in robots also exist with the default sweep counts as compile-time loop bounds
+  if (MD::kStatic && a.pgs_iters == kStdPgsIters && a.pgs_normal_iters == kStdPgsNormalIters)
+    hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, false>), grid, block, 0, s, a);
 }
 
 template <typename R, int UNIT>

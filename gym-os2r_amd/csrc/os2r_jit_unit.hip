@@ -24,9 +24,13 @@ using JitReal = OS2R_REAL;
 using JitModel = StModel<JitReal, 100>;
 }  // namespace os2r
 
+// NAME: sweep counts read from the handle; NAME_s: the default counts as compile-time loop bounds
 #define OS2R_JIT_KERNEL(NAME, CONTACT, DR)                                                        \
   extern "C" __global__ OS2R_STEP_KERNEL_ATTRS(OS2R_REAL) void NAME(const os2r::StepArgs<os2r::JitReal> A) { \
-    os2r::step_body<os2r::JitReal, os2r::JitModel, CONTACT, DR>(A);                               \
+    os2r::step_body<os2r::JitReal, os2r::JitModel, CONTACT, DR, false>(A);                        \
+  }                                                                                               \
+  extern "C" __global__ OS2R_STEP_KERNEL_ATTRS(OS2R_REAL) void NAME##_s(const os2r::StepArgs<os2r::JitReal> A) { \
+    os2r::step_body<os2r::JitReal, os2r::JitModel, CONTACT, DR, true>(A);                         \
   }
 
 #if OS2R_JIT_CONTACT

@@ -303,8 +303,9 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 }
 
 // One env-step of this wave's 64 environments: the body of every step kernel (the templated ones below and
-// the model-specialised ones of os2r_jit_unit.hip).
-template <typename T, typename MD, bool CONTACT, bool DR>
+// the model-specialised ones of os2r_jit_unit.hip).  STD_SWEEPS: the solver's sweep counts are the default
+// ones and known at compile time (the launcher checks the handle's configuration).
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false>
 __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
   __shared__ T tile[lds_words<NQ>() + (CONTACT && MD::CMASK != 0u ? kCandWords : 0)];
@@ -361,7 +362,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #endif
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin, A.pgs_iters, A.pgs_normal_iters, tile, cand_lds
+    substep<T, MD, CONTACT, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
+                                STD_SWEEPS ? kStdPgsIters : A.pgs_iters, STD_SWEEPS ? kStdPgsNormalIters : A.pgs_normal_iters,
+                                tile, cand_lds
 #ifdef OS2R_STAMPS
                                 , stamps, stamp_prev
 #endif
@@ -430,9 +433,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #define OS2R_STEP_KERNEL_ATTRS(REAL) \
   __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
 
-template <typename T, typename MD, bool CONTACT, bool DR>
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS>
 __global__ OS2R_STEP_KERNEL_ATTRS(T) void step_kernel(const StepArgs<T> A) {
-  step_body<T, MD, CONTACT, DR>(A);
+  step_body<T, MD, CONTACT, DR, STD_SWEEPS>(A);
 }
 
 // ----------------------------------------------------------------------------------------
