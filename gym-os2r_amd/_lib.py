@@ -12,7 +12,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libos2r.so")
+LIB_PATH = os.environ.get("OS2R_LIBRARY") or os.path.join(_HERE, "libos2r.so")   # OS2R_LIBRARY: A/B builds of the same ABI
 _lib = None
 
 # every symbol include/os2r.h declares
