@@ -750,12 +750,11 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // vector per row serves both the residual and the update, and because Lc is lower triangular
   // G_r of a contact on body b (and of the friction row of joint b) has only b+1 non-zeros.
   // This halves the per-row storage and work of the sweep compared with keeping J_r and
-  // Minv J_r^T; the rows live in the wave's LDS (the articulated-body slots are dead by now).
+  // Minv J_r^T.  The rows are written straight into registers (Gr) and stay there through the sweeps;
+  // only the factor is mirrored to LDS (the articulated-body slots are dead by now) for the row set-up.
   constexpr int NB = NQ;
   constexpr int kLc = 0;                       // Lc[i][k], k <= i, at kLc + i*(i+1)/2 + k
-  constexpr int kG = NQ * (NQ + 1) / 2;        // rows of body b at kG + 3*b*(b+1)/2 + row*(b+1) + k
   auto Lcs = [&](int i, int k) -> T& { return L(kLc + i * (i + 1) / 2 + k); };
-  auto Gs = [&](int b, int row, int k) -> T& { return L(kG + 3 * b * (b + 1) / 2 + row * (b + 1) + k); };
   T fb[NQ];   // joint friction impulse bound
   T mub[NB];  // ground friction coefficient of the bodies that can touch
 #pragma unroll
@@ -801,6 +800,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   OS2R_STAMP(3);
   // ---- 5. ground contact candidates -> one point contact per body ----
   T dn[NB], dx[NB], dy[NB], erv[NB];  // dn/dx/dy: reciprocal of J Minv J^T = |G_r|^2 per row (0: row off)
+  T Gr[NB][3][NQ];                    // the rows G = J Lc, held in registers through the sweeps
   bool act[NB];
   bool wave_act[NB];
 #pragma unroll
@@ -939,7 +939,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
             for (int j = k; j < NQ; ++j)
               if (j <= b) { const T l = lcb[j][k]; gn += Jn[j] * l; gx += Jx[j] * l; gy += Jy[j] * l; }
-            Gs(b, 0, k) = gn; Gs(b, 1, k) = gx; Gs(b, 2, k) = gy;
+            Gr[b][0][k] = gn; Gr[b][1][k] = gx; Gr[b][2][k] = gy;
             sdn += gn * gn; sdx += gx * gx; sdy += gy * gy;
           }
         }
@@ -972,21 +972,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // at mu ~ 1 (Painleve) and is kept for experiments only.
   // A row that is switched off has reciprocal rd == 0: lam = l - res*0 = l, and l already lies
   // inside its box, so the row reproduces itself without any select.
-  // The rows G are constant over the sweeps: they are fetched from LDS once, ahead of the loops.
-  // (Fetching them inside the sweep leaves every row waiting a full LDS round trip, which at
-  // one wave per SIMD nothing hides: that was half of the solver's time.)
-  T Gr[NB][3][NQ];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (!((CMASK >> b) & 1u)) continue;
-    if (wave_act[b]) {
-#pragma unroll
-      for (int row = 0; row < 3; ++row)
-#pragma unroll
-        for (int k = 0; k < NQ; ++k)
-          if (k <= b) Gr[b][row][k] = Gs(b, row, k);
-    }
-  }
+  // The rows G are constant over the sweeps and live in registers (Gr, written by the row set-up): reading
+  // them from LDS inside the sweep left every row waiting a full round trip, which at one wave per SIMD
+  // nothing hides (that was half of the solver's time); parking them in LDS between set-up and sweeps
+  // cost a wait too (+1.2 % without it).
   auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper) {
     T g[NQ];
     T res = -target;

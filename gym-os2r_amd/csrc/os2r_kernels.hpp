@@ -288,8 +288,8 @@ __device__ __forceinline__ void store_obs_tile(T* __restrict__ dst, const T (&ob
 // observation tile of the coalesced [N][D] store.
 template <int NQ>
 constexpr int lds_words() {
-  // contact rows G (3 rows x (b+1) per body) + Cholesky factor of Minv / per-joint ABA data
-  constexpr int rows = 3 * NQ * (NQ + 1) / 2 + NQ * (NQ + 1) / 2, aba = 8 * NQ;
+  // Cholesky factor of Minv / per-joint ABA data (U, 1/D, u)
+  constexpr int rows = NQ * (NQ + 1) / 2, aba = 8 * NQ;
   constexpr int m = rows > aba ? rows : aba;
   return kWave * (m > OS2R_MAX_OBS ? m : OS2R_MAX_OBS);
 }
