@@ -1013,23 +1013,22 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   const bool fixed_box = pgs_normal_iters > 0;
   // every row fetched above has landed before the sweeps start (otherwise the waits sit inside them)
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-  for (int it = 0; it < pgs_normal_iters; ++it) {
+  T limfix[NB];
+  // The bodies in contact are nearly always a suffix of the chain (the distal links reach the
+  // ground first; a fallen robot lies on links 2..4), so both phases exist once per suffix as
+  // straight-line code -- no per-body branch, no copies at the joins -- besides the general form.
+  auto normal_sweep = [&](auto first) {
+    constexpr int kFirst = decltype(first)::value;   // < 0: general form, test every body
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
-      if (wave_act[b]) contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
+      if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
     }
     joint_rows();
-  }
-  OS2R_STAMP(7);
-  T limfix[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
-  // The bodies in contact are nearly always a suffix of the chain (the distal links reach the
-  // ground first; a fallen robot lies on links 2..4), so the sweep exists once per suffix as
-  // straight-line code -- no per-body branch, no copies at the joins -- besides the general form.
+  };
   auto sweep = [&](auto coupled, auto first) {
-    constexpr int kFirst = decltype(first)::value;   // < 0: general form, test every body
+    constexpr int kFirst = decltype(first)::value;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
@@ -1049,14 +1048,20 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     if (!((CMASK >> b) & 1u)) continue;
     if (wave_act[b]) { is_suffix = is_suffix && first_act == next_cand_body<CMASK, NB>(b); first_act = b; }
   }
-  auto fixed_sweeps = [&](auto first) {
+  auto solve_fixed_box = [&](auto first) {
+    for (int it = 0; it < pgs_normal_iters; ++it) normal_sweep(first);
+    OS2R_STAMP(7);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
 #pragma unroll 2
     for (int it = 0; it < pgs_iters; ++it) sweep(std::false_type{}, first);
   };
   if (!fixed_box) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) limfix[b] = 0;
     for (int it = 0; it < pgs_iters; ++it) sweep(std::true_type{}, std::integral_constant<int, -1>{});
-  } else if (!(is_suffix && first_act < NB && for_body<0, NB, CMASK>(first_act, fixed_sweeps))) {
-    fixed_sweeps(std::integral_constant<int, -1>{});
+  } else if (!(is_suffix && first_act < NB && for_body<0, NB, CMASK>(first_act, solve_fixed_box))) {
+    solve_fixed_box(std::integral_constant<int, -1>{});
   }
   OS2R_STAMP(8);
   // back to joint velocities: v += Lc (y - y0)
