@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_STAMP(7);
 #pragma unroll
     for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
-#pragma unroll 2
+#pragma unroll 4
     for (int it = 0; it < pgs_iters; ++it) sweep(std::false_type{}, first);
   };
   if (!fixed_box) {
