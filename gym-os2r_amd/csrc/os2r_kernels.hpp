@@ -360,9 +360,10 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #ifdef OS2R_STAMPS
   unsigned long long stamps[kStamps] = {}, stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
+  T sn[NQ], cs[NQ];   // sin/cos of the joint angles, carried from one physics iteration to the next
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR>(md, par, q, qd, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
+    substep<T, MD, CONTACT, DR>(md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
                                 STD_SWEEPS ? kStdPgsIters : A.pgs_iters, STD_SWEEPS ? kStdPgsNormalIters : A.pgs_normal_iters,
                                 tile, cand_lds
 #ifdef OS2R_STAMPS
