@@ -701,14 +701,24 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   }
 
   OS2R_STAMP(1);
-  // ---- 3. inverse of (M + dt*diag(d)): unit-torque sweeps, upper triangle ----
-  // Column k is the response to a unit torque at joint k.  All columns are swept together,
-  // joint by joint, so every joint rotation, U_i and 1/D_i is fetched once per pass.
-  T Mi[NQ][NQ];
+  // ---- 3. factor of the inverse of M~ = M + dt*diag(d), straight from the articulated-body quantities ----
+  // The inward pass maps joint torques to the "innovations" eps = A tau with A unit upper triangular
+  // (eps_i collects the torques of joint i and of its descendants k > i), the outward pass maps
+  // nu = D^-1 eps to accelerations with A^T, so
+  //        M~^-1 = A^T D^-1 A = Lc Lc^T,   Lc[r][c] = A[c][r] / sqrt(D_c)   (lower triangular, r >= c).
+  // Lc is therefore THE Cholesky factor of M~^-1 (it is unique), and it costs the unit-torque inward
+  // sweep only: neither M~^-1 itself, nor its outward sweep, nor a factorisation is needed.
+  // A[i][k] = uk[k][i] is the joint-space force that a unit torque at joint k >= i leaves at joint i.
+  constexpr int NB = NQ;
+  constexpr int kLc = 0;                       // Lc[i][k], k <= i, at kLc + i*(i+1)/2 + k (LDS mirror, after the pass)
+  auto Lcs = [&](int i, int k) -> T& { return L(kLc + i * (i + 1) / 2 + k); };
+  T Lc[NQ][NQ];   // lower triangle, also mirrored to LDS for the contact-row setup
+  T Ldi[NQ];      // 1 / Lc[i][i] = sqrt(D_i)
   {
     T uk[NQ][NQ];            // uk[k][i]: joint-space force of column k at joint i (i <= k)
     V3<T> pn_[NQ], pf_[NQ];  // bias force of column k, expressed in the current body
-    // inward: bodies NQ-1 .. 0
+    // inward: bodies NQ-1 .. 0; all columns are swept together, so every joint rotation, U_i and 1/D_i
+    // is fetched once
 #pragma unroll
     for (int i = NQ - 1; i >= 0; --i) {
       const V3<T> Ua = ldv(kUa, i), Ul = ldv(kUl, i);
@@ -725,43 +735,28 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           const V3<T> f = rmul(Ri, pf_[k]);
           const V3<T> n = rmul(Ri, pn_[k]) + cross(r, f);
           uk[k][i] = -comp(n, md.axis(i));
-          const T s_ = uk[k][i] * di;
-          pn_[k] = n + s_ * Ua;
-          pf_[k] = f + s_ * Ul;
+          if (i > 0) {                         // nothing is propagated below the base joint
+            const T s_ = uk[k][i] * di;
+            pn_[k] = n + s_ * Ua;
+            pf_[k] = f + s_ * Ul;
+          }
         }
       }
-      pn_[i] = di * Ua;
-      pf_[i] = di * Ul;
-    }
-    OS2R_STAMP(19);
-    // outward: accelerations of every column, bodies 0 .. k
-    V3<T> aa[NQ], al[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) { aa[k] = mk<T>(0, 0, 0); al[k] = mk<T>(0, 0, 0); }
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const V3<T> Ua = ldv(kUa, i), Ul = ldv(kUl, i);
-      const T di = L(kDi + i);
-      T Ri[9];
-      const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
-      if (i > 0) joint_rotation<T>(md, i, sn[i], cs[i], Ri);
-#pragma unroll
-      for (int k = i; k < NQ; ++k) {
-        if (i > 0) {
-          const V3<T> na = rtmul(Ri, aa[k]);
-          al[k] = rtmul(Ri, al[k] + cross(aa[k], r));
-          aa[k] = na;
-        }
-        const T x = (uk[k][i] - dot(Ua, aa[k]) - dot(Ul, al[k])) * di;
-        Mi[i][k] = x;
-        Mi[k][i] = x;
-        add_comp(aa[k], md.axis(i), x);
+      if (i > 0) {
+        pn_[i] = di * Ua;
+        pf_[i] = di * Ul;
       }
+      // column i of the factor: A[i][r] / sqrt(D_i) for the rows r >= i
+      Ldi[i] = rsqrt_t(di);                    // sqrt(D_i)
+      const T sdi = di * Ldi[i];               // 1 / sqrt(D_i)
+#pragma unroll
+      for (int r = i; r < NQ; ++r) Lc[r][i] = r == i ? sdi : uk[r][i] * sdi;
     }
   }
+  OS2R_STAMP(19);
 
   OS2R_STAMP(2);
-  // ---- 4. whitening: Minv = Lc Lc^T (Cholesky, lower), y = Lc^-1 v ----
+  // ---- 4. whitening: y = Lc^-1 v ----
   // The constraint rows are solved in the coordinates y: for a row with Jacobian J_r,
   // J_r v = G_r y and the velocity response Minv J_r^T dl = Lc (G_r^T dl) with G_r = J_r Lc, so one
   // vector per row serves both the residual and the update, and because Lc is lower triangular
@@ -769,9 +764,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // This halves the per-row storage and work of the sweep compared with keeping J_r and
   // Minv J_r^T.  The rows are written straight into registers (Gr) and stay there through the sweeps;
   // only the factor is mirrored to LDS (the articulated-body slots are dead by now) for the row set-up.
-  constexpr int NB = NQ;
-  constexpr int kLc = 0;                       // Lc[i][k], k <= i, at kLc + i*(i+1)/2 + k
-  auto Lcs = [&](int i, int k) -> T& { return L(kLc + i * (i + 1) / 2 + k); };
   T fb[NQ];   // joint friction impulse bound
   T mub[NB];  // ground friction coefficient of the bodies that can touch
 #pragma unroll
@@ -781,34 +773,19 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   __builtin_amdgcn_sched_barrier(kPinVmem);   // requested here, needed by the solver
   T y[NQ];
   T idj[NQ];  // reciprocal of Minv[j][j] = |row j of Lc|^2 (joint friction rows)
-  T Lc[NQ][NQ];  // lower triangle, also mirrored to LDS for the contact-row setup
-  {
-    T Ldi[NQ];
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      T sdiag = Mi[j][j];
+  for (int j = 0; j < NQ; ++j) {
+    T mjj = 0;
 #pragma unroll
-      for (int k = 0; k < j; ++k) sdiag -= Lc[j][k] * Lc[j][k];
-      Ldi[j] = rsqrt_t(sdiag);
-      Lc[j][j] = sdiag * Ldi[j];
-      Lcs(j, j) = Lc[j][j];
+    for (int k = 0; k <= j; ++k) { mjj += Lc[j][k] * Lc[j][k]; Lcs(j, k) = Lc[j][k]; }
+    idj[j] = mjj > T(0) ? rcp_t(mjj) : T(0);
+  }
 #pragma unroll
-      for (int i = j + 1; i < NQ; ++i) {
-        T sod = Mi[i][j];
+  for (int i = 0; i < NQ; ++i) {
+    T acc_ = vs[i];
 #pragma unroll
-        for (int k = 0; k < j; ++k) sod -= Lc[i][k] * Lc[j][k];
-        Lc[i][j] = sod * Ldi[j];
-        Lcs(i, j) = Lc[i][j];
-      }
-      idj[j] = Mi[j][j] > T(0) ? rcp_t(Mi[j][j]) : T(0);
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      T acc_ = vs[i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) acc_ -= Lc[i][k] * y[k];
-      y[i] = acc_ * Ldi[i];
-    }
+    for (int k = 0; k < i; ++k) acc_ -= Lc[i][k] * y[k];
+    y[i] = acc_ * Ldi[i];
   }
   T y0[NQ];  // only the change of y is mapped back, so an idle solve leaves v bit-identical
 #pragma unroll
