@@ -479,7 +479,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T (&sn)[MD::NQ], T (&cs)[MD::NQ], bool first_iteration,
                                         T tau_hip, T tau_knee, T dt, T erp,
                                         T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds,
-                                        const T* __restrict__ cand_lds
+                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst
 #ifdef OS2R_STAMPS
                                         , unsigned long long (&stamps)[kStamps], unsigned long long& stamp_prev
 #endif
@@ -861,7 +861,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
           for (int kk = k0; kk < k1; kk += CH) {
             T d[3 * CH];
 #pragma unroll
-            for (int j = 0; j < 3 * CH; ++j) d[j] = (kk + j / 3 < k1) ? cand_lds[3 * kk + j] : T(0);
+            for (int j = 0; j < 3 * CH; ++j) d[j] = (kk + j / 3 < k1) ? mconst->cand_p[kk + j / 3][j % 3] : T(0);   // scalar loads: wave-uniform operands
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
               if (kk + c < k1) {

@@ -308,14 +308,17 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false>
 __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
-  __shared__ T tile[lds_words<NQ>() + (CONTACT && MD::CMASK != 0u ? kCandWords : 0)];
+  // run-time models scan a wave-shared LDS copy of the candidate table; the compiled-in ones read the
+  // (wave-uniform) coordinates through scalar loads, straight into the operands of the scan
+  constexpr bool kCandInLds = CONTACT && MD::CMASK != 0u && !MD::kStatic;
+  __shared__ T tile[lds_words<NQ>() + (kCandInLds ? kCandWords : 0)];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
   const long long e = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
   const MD md = make_model<T, MD>(A);
   T* cand_lds = tile + lds_words<NQ>();
-  if constexpr (CONTACT && MD::CMASK != 0u) {
+  if constexpr (kCandInLds) {
     const int nc3 = 3 * md.cand_begin(NQ);
     for (int k = lane; k < nc3; k += kWave) cand_lds[k] = md.cand(k / 3, k % 3);
     __syncthreads();
@@ -365,7 +368,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
     substep<T, MD, CONTACT, DR>(md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
                                 STD_SWEEPS ? kStdPgsIters : A.pgs_iters, STD_SWEEPS ? kStdPgsNormalIters : A.pgs_normal_iters,
-                                tile, cand_lds
+                                tile, cand_lds, as_const(A.model)
 #ifdef OS2R_STAMPS
                                 , stamps, stamp_prev
 #endif
