@@ -226,6 +226,16 @@ def main():
             out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                                     "frac": tf / peak, "flops_per_env_step": flops["flops_per_env_step"],
                                     "source": flops.get("source")}
+            # what the kernel actually executes (it reaches the specification's result with fewer operations:
+            # whitened rows, factor of the inverse mass matrix straight from the ABA): PMC-counted, C4 f64 only
+            ip = os.path.join(ROOT, "profiles", "r01_issue_breakdown.json")
+            if os.path.exists(ip) and args.workload == "C4" and args.dtype == "f64":
+                with open(ip) as f:
+                    counted = json.load(f).get("fp64_flops_per_env_step_counted")
+                if counted:
+                    tfe = counted * args.envs_per_gpu / per_launch_s / 1e12
+                    out["roofline_valu"].update({"executed_flops_per_env_step": counted, "achieved_executed": tfe,
+                                                 "frac_executed": tfe / peak})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)
