@@ -12,13 +12,17 @@ from __future__ import annotations
 import json
 import os
 from copy import copy
-from functools import reduce
-from operator import getitem
 
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 
+def _split(xpath: str):
+    return [part for part in xpath.strip("/").split("/")]
+
+
 class BaseConfig:
+    """A nested dict addressed by '/'-separated paths (no wildcards, no type enforcement)."""
+
     def __init__(self, path: str):
         if not os.path.isabs(path):
             path = os.path.join(_ASSETS, path)
@@ -29,20 +33,21 @@ class BaseConfig:
             else:
                 self.config_dict = json.load(f)
 
+    def _parent(self, parts, create: bool):
+        node = self.config_dict
+        for name in parts[:-1]:
+            node = node.setdefault(name, {}) if create else node[name]     # KeyError on a missing branch when reading
+        return node
+
     def set_config(self, value, xpath: str):
-        keys = xpath.strip("/").split("/")
-        d = self.config_dict
-        for k in keys[:-1]:
-            try:
-                d = d[k]
-            except KeyError:
-                d[k] = {}
-                d = d[k]
-        d[keys[-1]] = value
+        """Write ``value`` at ``xpath``; branches that do not exist yet are created."""
+        parts = _split(xpath)
+        self._parent(parts, create=True)[parts[-1]] = value
 
     def get_config(self, xpath: str):
-        keys = xpath.strip("/").split("/")
-        return copy(reduce(getitem, keys[:-1], self.config_dict)[keys[-1]])
+        """Shallow copy of the node at ``xpath`` (``KeyError`` if it does not exist)."""
+        parts = _split(xpath)
+        return copy(self._parent(parts, create=False)[parts[-1]])
 
 
 class SettingsConfig(BaseConfig):
