@@ -14,8 +14,8 @@
 //   1. joint transforms, body velocities
 //   2. articulated-body algorithm (Featherstone) with joint damping taken
 //      implicitly in the projected articulated inertia  D_i = S'I^A S + dt*d_i
-//   3. inverse of the damping-augmented mass matrix from unit-torque sweeps over
-//      the same factorisation (upper triangle only, by symmetry)
+//   3. the lower-triangular factor Lc of the inverse of the damping-augmented mass matrix
+//      (M~^-1 = Lc Lc^T), read off the same factorisation with one unit-torque inward sweep
 //   4. v* = qd + dt*qdd
 //   5. ground contact: per body, the centroid of its collision candidate points that are
 //      within `margin` of the ground, weighted by (margin - z), gives one frictional point
@@ -526,8 +526,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   OS2R_STAMP(0);
   // Per-lane LDS slots (slot-major: lds[slot * 64 + lane], conflict free).  During the
   // articulated-body passes they hold the per-joint quantities that must survive from one pass
-  // to the next (U = I^A S, 1/D, u); afterwards the same storage holds the Cholesky factor of
-  // the inverse mass matrix and the rows of the contact problem.  Keeping these out of the
+  // to the next (U = I^A S, 1/D, u); afterwards the same storage holds the triangular factor of
+  // the inverse mass matrix (mirror for the contact-row set-up).  Keeping these out of the
   // register file is what keeps the fp64 kernel free of scratch spills.
   const int lane_ = threadIdx.x;
   auto L = [&](int slot) -> T& { return lds[slot * kWave + lane_]; };
