@@ -265,6 +265,7 @@ def test_jit_builds_a_code_object_for_a_custom_robot(monkeypatch):
     assert "struct Tables<100>" in src and f"static constexpr int nq = {model['nq']};" in src
     assert float(model["mass"][2]).hex() in src                      # exact hex-float literals
     path = jit.build(ms, abi.F64, True)
+    assert os.path.getsize(jit.build(ms, abi.F32, True)) > 100_000          # the f32 kernels of the same robot
     assert os.path.getsize(path) > 100_000
     blob = open(path, "rb").read()
     assert b"os2r_jit_step_c1_d0" in blob and b"os2r_jit_step_c1_d1" in blob and b"os2r_jit_step_c0_d0" not in blob
