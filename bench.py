@@ -140,6 +140,9 @@ def main():
                     help="process-group backend for the barrier / max-time reduction (nccl = RCCL; gloo lets several "
                          "ranks share one GPU when rehearsing the multi-rank path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--gather-obs", action="store_true",
+                    help="also gather obs / reward / done of every step to rank 0 (the optional RCCL collective of "
+                         "SURVEY 8e; off the step path, so off by default): one launch + one gather per step")
     args = ap.parse_args()
     if args.envs_per_gpu is None:
         args.envs_per_gpu = 4096 if args.workload == "C2" else 65536
@@ -183,7 +186,21 @@ def main():
     sim.bench_steps(max(args.warmup, 1)) if args.warmup > 0 else None
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = sim.bench_steps(args.steps)           # K launches, HIP events on the launch stream
+    if not args.gather_obs:
+        kernel_ms = sim.bench_steps(args.steps)       # K launches, HIP events on the launch stream
+    else:
+        from gym_os2r_amd.distributed import gather_to_rank0
+        host = use_dist and args.backend == "gloo"    # gloo gathers host tensors
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kernel_ms = 0.0
+        for _ in range(args.steps):
+            ev0.record()
+            obs, rew, done, _ = sim.step(None, want_terminal=False)
+            ev1.record()
+            for t in (obs, rew, done):
+                gather_to_rank0(t.cpu() if host else t, args.envs_per_gpu * world)
+            ev1.synchronize()
+            kernel_ms += ev0.elapsed_time(ev1)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -207,7 +224,8 @@ def main():
                        "envs_per_gpu": args.envs_per_gpu, "total_envs": total_envs, "task_mode": WORKLOADS[args.workload][0],
                        "substeps": int(cfg.substeps), "dt": float(cfg.dt), "pgs_sweeps": [int(cfg.pgs_normal_iters), int(cfg.pgs_iters)],
                        "contact": bool(cfg.contact), "domain_randomisation": WORKLOADS[args.workload][3],
-                       "actions": "U(-1,1) Philox on device", "sharding": f"envs x{world}, no step-path collective"},
+                       "actions": "U(-1,1) Philox on device",
+                       "sharding": f"envs x{world}, " + ("obs/reward/done gathered to rank 0 every step" if args.gather_obs else "no step-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
