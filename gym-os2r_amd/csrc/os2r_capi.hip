@@ -45,6 +45,19 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Every entry point works on the device of its handle and leaves the caller's current device as it found it
+// (a process may hold handles on several GPUs; torch keeps its own idea of the current device).
+struct DeviceGuard {
+  int prev = -1, dev = -1;
+  explicit DeviceGuard(int device) : dev(device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+
 struct SimBase {
   Os2rConfig cfg;
   std::string err;
@@ -384,6 +397,7 @@ int os2r_destroy(Os2rSim* sim) {
 
 int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* stream) {
   if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   return sim->cfg.dtype == OS2R_F64 ? do_reset<double>(sim, mask_dev, obs_dev, (hipStream_t)stream)
                                     : do_reset<float>(sim, mask_dev, obs_dev, (hipStream_t)stream);
 }
@@ -391,6 +405,7 @@ int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* strea
 int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev, uint8_t* done_dev,
               void* term_obs_dev, void* stream) {
   if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   return sim->cfg.dtype == OS2R_F64
              ? do_step<double>(sim, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, (hipStream_t)stream)
              : do_step<float>(sim, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, (hipStream_t)stream);
@@ -398,6 +413,7 @@ int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward
 
 int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream) {
   if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   const size_t b = (size_t)sim->nq * sim->cfg.num_envs * sim->esz;
   if (q_dev) HIP_TRY(sim, hipMemcpyAsync(q_dev, sim->q, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (qd_dev) HIP_TRY(sim, hipMemcpyAsync(qd_dev, sim->qd, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -406,6 +422,7 @@ int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream) {
 
 int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* stream) {
   if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   const size_t b = (size_t)sim->nq * sim->cfg.num_envs * sim->esz;
   if (q_dev) HIP_TRY(sim, hipMemcpyAsync(sim->q, q_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (qd_dev) HIP_TRY(sim, hipMemcpyAsync(sim->qd, qd_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -414,6 +431,7 @@ int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* st
 
 int os2r_get_action_history(Os2rSim* sim, int which, void* out_dev, void* stream) {
   if (!sim || which < 0 || which > 1 || !out_dev) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   const size_t b = 2 * (size_t)sim->cfg.num_envs * sim->esz;
   HIP_TRY(sim, hipMemcpyAsync(out_dev, (char*)sim->hist + which * b, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return OS2R_OK;
@@ -421,6 +439,7 @@ int os2r_get_action_history(Os2rSim* sim, int which, void* out_dev, void* stream
 
 int os2r_set_action_history(Os2rSim* sim, int which, const void* in_dev, void* stream) {
   if (!sim || which < 0 || which > 1 || !in_dev) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   const size_t b = 2 * (size_t)sim->cfg.num_envs * sim->esz;
   HIP_TRY(sim, hipMemcpyAsync((char*)sim->hist + which * b, in_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return OS2R_OK;
@@ -429,6 +448,7 @@ int os2r_set_action_history(Os2rSim* sim, int which, const void* in_dev, void* s
 int os2r_set_params(Os2rSim* sim, int field, const void* src_dev, void* stream) {
   void* base; int count;
   if (!sim || !src_dev || param_view(sim, field, &base, &count)) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   HIP_TRY(sim, hipMemcpyAsync(base, src_dev, (size_t)count * sim->cfg.num_envs * sim->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   sim->dr = true;
   return OS2R_OK;
@@ -437,12 +457,14 @@ int os2r_set_params(Os2rSim* sim, int field, const void* src_dev, void* stream) 
 int os2r_get_params(Os2rSim* sim, int field, void* dst_dev, void* stream) {
   void* base; int count;
   if (!sim || !dst_dev || param_view(sim, field, &base, &count)) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   HIP_TRY(sim, hipMemcpyAsync(dst_dev, base, (size_t)count * sim->cfg.num_envs * sim->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return OS2R_OK;
 }
 
 int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_dev, uint8_t* pose_dev, void* stream) {
   if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   const size_t N = (size_t)sim->cfg.num_envs;
   if (steps_dev) HIP_TRY(sim, hipMemcpyAsync(steps_dev, sim->steps, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (episode_dev) HIP_TRY(sim, hipMemcpyAsync(episode_dev, sim->episode, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -478,6 +500,7 @@ int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t d
 
 int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void* stream) {
   if (!sim || !dst) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   HIP_TRY(sim, hipMemcpyAsync(dst, sim->violations, 4, hipMemcpyDefault, (hipStream_t)stream));
   if (clear) HIP_TRY(sim, hipMemsetAsync(sim->violations, 0, 4, (hipStream_t)stream));
   return OS2R_OK;
@@ -497,6 +520,7 @@ int os2r_set_step_count(Os2rSim* sim, uint64_t value) {
 
 int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) {
   if (!sim || nsteps < 1 || !elapsed_ms) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(sim, hipEventRecord(sim->ev0, st));
   for (int k = 0; k < nsteps; ++k) {
