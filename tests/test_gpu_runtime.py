@@ -1,6 +1,7 @@
 """Env-level API on the GPU: the assertions of the reference's tests/tests_general.py
 (:12-160) restated for the batched runtime, the VecEnv surface, and the N=1 ScenarIO facade."""
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from gym_os2r_amd.randomizers.monopod import MonopodEnvRandomizer
 from gym_os2r_amd.randomizers.monopod_no_rand import MonopodEnvNoRandomizer
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -222,3 +224,30 @@ def test_device_actions_are_validated_without_stalling(torch_mod):
     with pytest.raises(AssertionError):
         e1.close()
     e2.close(); env.close()
+
+
+@pytest.mark.gpu
+def test_bench_prints_the_contract_line():
+    """bench.py: one JSON line with the contract keys, the roofline objects and the CPU baseline (short run)."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5",
+                          "--cpu-seconds", "1.0", "--cpu-envs", "256"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["unit"] == "env-steps/s"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert abs(d["value"] - 65536 * 30 / (d["ms_per_step"] * 30 * 1e-3)) / d["value"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
