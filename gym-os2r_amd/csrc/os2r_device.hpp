@@ -313,6 +313,8 @@ __device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
 
 __device__ __forceinline__ double fmax_t(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float fmax_t(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fabs_t(double x) { return fabs(x); }
 __device__ __forceinline__ float fabs_t(float x) { return fabsf(x); }
 
@@ -499,7 +501,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     bool ok = true, small = !first_iteration;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) { ok = ok && sincos_in_range(q[i]); small = small && fabs_t(dt * qd[i]) < T(0.01); }
-    if (__ballot(!small) == 0ull) {
+    // The choice is made per lane (divergent branches; a wave whose lanes agree, the usual case, executes one
+    // side only): what a lane computes must not depend on who shares its wave.
+    if (small) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const T d = dt * qd[i], z = d * d;
@@ -513,8 +517,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         sn[i] = s0 + __builtin_fma(c0, sd, s0 * cm);
         cs[i] = c0 + __builtin_fma(-s0, sd, c0 * cm);
       }
-    } else if (__ballot(!ok) == 0ull) {
-      // one wave-wide range check for all joints, so the five evaluations are straight-line code
+    } else if (ok) {
+      // one range check for all joints of the lane, so the five evaluations are straight-line code
 #pragma unroll
       for (int i = 0; i < NQ; ++i) sincos_fast(q[i], sn[i], cs[i]);
     } else {
@@ -785,7 +789,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     T acc_ = vs[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) acc_ -= Lc[i][k] * y[k];
-    y[i] = acc_ * Ldi[i];
+    y[i] = opaque(acc_ * Ldi[i]);   // a plain value for the sweeps: its product is not to be fused into their updates
   }
   T y0[NQ];  // only the change of y is mapped back, so an idle solve leaves v bit-identical
 #pragma unroll
@@ -971,37 +975,39 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // nothing hides (that was half of the solver's time); parking them in LDS between set-up and sweeps
   // cost a wait too (+1.2 % without it).
   auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper) {
+    // Explicit fused operations, in source order: with contraction left to the compiler a sum of two products
+    // (`g0*y0 + g1*y1` when the target is zero) has two fused forms, and which one it picks differs between the
+    // specialised and the general sweep code -- a lane's result would depend on its company in the wave.
     T g[NQ];
     T res = -target;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (k <= b) { g[k] = Gr[b][row][k]; res += g[k] * y[k]; }
-    T lam = l - res * rd;
+      if (k <= b) { g[k] = Gr[b][row][k]; res = fma_t(g[k], y[k], res); }
+    T lam = fma_t(-res, rd, l);
     lam = lam < lo ? lo : lam;
     if (upper) lam = lam > hi ? hi : lam;
     const T dl = lam - l;
     l = lam;
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
-      if (k <= b) y[k] += g[k] * dl;
+      if (k <= b) y[k] = fma_t(g[k], dl, y[k]);
   };
   auto joint_rows = [&]() {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       // joint Coulomb friction row: J = e_j, G = row j of Lc, d = Minv[j][j]
-      // (two partial sums: the sweep is a chain of dependent operations, keep it short)
-      T res = 0;
+      T res = Lc[j][0] * y[0];
 #pragma unroll
-      for (int k = 0; k < NQ; ++k)
-        if (k <= j) res += Lc[j][k] * y[k];
-      T lam = lf[j] - res * idj[j];
+      for (int k = 1; k < NQ; ++k)
+        if (k <= j) res = fma_t(Lc[j][k], y[k], res);
+      T lam = fma_t(-res, idj[j], lf[j]);
       lam = lam < -fb[j] ? -fb[j] : lam;
       lam = lam > fb[j] ? fb[j] : lam;
       const T dl = lam - lf[j];
       lf[j] = lam;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
-        if (k <= j) y[k] += Lc[j][k] * dl;
+        if (k <= j) y[k] = fma_t(Lc[j][k], dl, y[k]);
     }
   };
   const bool fixed_box = pgs_normal_iters > 0;
