@@ -18,7 +18,7 @@ _lib = None
 # every symbol include/os2r.h declares
 SYMBOLS = ["os2r_abi_version", "os2r_create", "os2r_destroy", "os2r_reset", "os2r_step",
            "os2r_get_state", "os2r_set_state", "os2r_get_action_history", "os2r_set_action_history",
-           "os2r_set_params", "os2r_get_params", "os2r_get_episode_info", "os2r_get_action_violations",
+           "os2r_set_params", "os2r_get_params", "os2r_get_episode_info", "os2r_set_episode_info", "os2r_get_action_violations",
            "os2r_get_step_count",
            "os2r_set_step_count", "os2r_bench_steps", "os2r_model_is_compiled_in",
            "os2r_register_model_kernels", "os2r_last_error"]
@@ -50,6 +50,7 @@ def load():
     lib.os2r_set_params.argtypes = [vp, C.c_int, vp, vp]
     lib.os2r_get_params.argtypes = [vp, C.c_int, vp, vp]
     lib.os2r_get_episode_info.argtypes = [vp, vp, vp, vp, vp]
+    lib.os2r_set_episode_info.argtypes = [vp, vp, vp, vp, vp]
     lib.os2r_get_action_violations.argtypes = [vp, vp, C.c_int32, vp]
     lib.os2r_get_step_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.os2r_set_step_count.argtypes = [vp, C.c_uint64]

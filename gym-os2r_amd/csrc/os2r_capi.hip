@@ -472,6 +472,16 @@ int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_de
   return OS2R_OK;
 }
 
+int os2r_set_episode_info(Os2rSim* sim, const int32_t* steps_dev, const uint32_t* episode_dev, const uint8_t* pose_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
+  const size_t N = (size_t)sim->cfg.num_envs;
+  if (steps_dev) HIP_TRY(sim, hipMemcpyAsync(sim->steps, steps_dev, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (episode_dev) HIP_TRY(sim, hipMemcpyAsync(sim->episode, episode_dev, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (pose_dev) HIP_TRY(sim, hipMemcpyAsync(sim->pose, pose_dev, N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
 int os2r_model_is_compiled_in(const Os2rModel* model) {
   return model && os2r::static_model_id(*model) >= 0 ? 1 : 0;
 }

@@ -37,6 +37,8 @@ PYBIND11_MODULE(_os2r_py, m) {
   m.def("get_params", [](addr h, int f, addr d, addr st) { return os2r_get_params(H(h), f, P(d), P(st)); }, nogil);
   m.def("get_episode_info", [](addr h, addr s, addr e, addr p, addr st) {
     return os2r_get_episode_info(H(h), (int32_t*)P(s), (uint32_t*)P(e), (uint8_t*)P(p), P(st)); }, nogil);
+  m.def("set_episode_info", [](addr h, addr s, addr e, addr p, addr st) {
+    return os2r_set_episode_info(H(h), (const int32_t*)P(s), (const uint32_t*)P(e), (const uint8_t*)P(p), P(st)); }, nogil);
   m.def("get_action_violations", [](addr h, addr d, int clear, addr st) {
     return os2r_get_action_violations(H(h), (uint32_t*)P(d), clear, P(st)); }, nogil);
   m.def("get_step_count", [](addr h) { uint64_t v = 0; int rc = os2r_get_step_count(H(h), &v); return py::make_tuple(rc, v); });

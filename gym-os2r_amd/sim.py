@@ -69,6 +69,9 @@ class _PybindLib:
     def os2r_get_episode_info(self, h, s, e, p, st):
         return self.m.get_episode_info(self._a(h), self._a(s), self._a(e), self._a(p), self._a(st))
 
+    def os2r_set_episode_info(self, h, s, e, p, st):
+        return self.m.set_episode_info(self._a(h), self._a(s), self._a(e), self._a(p), self._a(st))
+
     def os2r_get_action_violations(self, h, d, clear, st):
         return self.m.get_action_violations(self._a(h), self._a(d), int(clear), self._a(st))
 
@@ -215,6 +218,32 @@ class HipSim:
         self._check(self._lib.os2r_get_episode_info(self._h, _ptr(steps), _ptr(epi), _ptr(pose), self._stream()),
                     "os2r_get_episode_info")
         return steps, epi, pose
+
+    def set_episode_info(self, steps=None, episode=None, pose=None):
+        s = None if steps is None else self._in(steps, (self.N,), torch.int32)
+        e = None if episode is None else self._in(episode, (self.N,), torch.int32)
+        p = None if pose is None else self._in(pose, (self.N,), torch.uint8)
+        self._check(self._lib.os2r_set_episode_info(self._h, _ptr(s), _ptr(e), _ptr(p), self._stream()), "os2r_set_episode_info")
+        torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+
+    # -- checkpoint / resume ----------------------------------------------------------------
+    def checkpoint(self) -> dict:
+        """Everything that determines the future of this handle, as device tensors (+ the step counter)."""
+        q, qd = self.get_state()
+        steps, episode, pose = self.episode_info()
+        return {"q": q, "qd": qd, "hist0": self.get_action_history(0), "hist1": self.get_action_history(1),
+                "params": {f: self.get_params(f) for f in (abi.PARAM_MASS_SCALE, abi.PARAM_DAMPING, abi.PARAM_FRICTION,
+                                                            abi.PARAM_MU, abi.PARAM_GRAVITY)},
+                "steps": steps, "episode": episode, "pose": pose, "step_count": self.step_count}
+
+    def restore(self, ck: dict):
+        """Continue from a `checkpoint()` (of this or of another handle with the same configuration)."""
+        self.set_state(ck["q"], ck["qd"])
+        self.set_action_history(0, ck["hist0"]); self.set_action_history(1, ck["hist1"])
+        for f, v in ck["params"].items():
+            self.set_params(f, v)
+        self.set_episode_info(ck["steps"], ck["episode"], ck["pose"])
+        self.step_count = ck["step_count"]
 
     def action_violations_into(self, dst: torch.Tensor, clear: bool = True):
         """Copy the running count of out-of-range caller actions into ``dst`` (one int32/uint32 element,

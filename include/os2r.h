@@ -238,6 +238,11 @@ int os2r_get_params(Os2rSim* sim, int field, void* dst_dev, void* stream);
  * id (uint8, info['reset_orientation']); any pointer may be NULL.               */
 int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_dev,
                           uint8_t* pose_dev, void* stream);
+/* The inverse (any pointer may be NULL): together with os2r_set_state, os2r_set_action_history, os2r_set_params
+ * and os2r_set_step_count it restores a handle exactly -- a checkpoint resumed on another handle continues bit
+ * for bit (the reference has no save/restore, only env.seed).                                              */
+int os2r_set_episode_info(Os2rSim* sim, const int32_t* steps_dev, const uint32_t* episode_dev,
+                          const uint8_t* pose_dev, void* stream);
 
 /* Global step counter that keys the on-device action RNG. */
 int os2r_get_step_count(Os2rSim* sim, uint64_t* out);
