@@ -287,3 +287,40 @@ def test_plain_cpp_program_drives_the_c_abi(torch_mod, tmp_path):
             h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert res["checksum"] == f"{h:016x}"
     sim.close()
+
+
+def test_handles_on_their_own_streams(torch_mod):
+    """Every call is ordered on the caller's current stream: two handles driven from two side streams, with the
+    host racing ahead, must give what the same handles give on the default stream."""
+    from helpers import make_config
+    from gym_os2r_amd.sim import HipSim
+    def cfg(seed):
+        return make_config("fixed_hip", "BalancingV1", True, reset_mode=abi.RESET_RANDOM, randomize_params=True,
+                           num_envs=4096, contact=True, seed=seed, max_episode_steps=13)[0]
+    ref = []
+    for seed in (1, 2):
+        sim = HipSim(cfg(seed)); sim.reset()
+        for _ in range(30):
+            out = sim.step(None)
+        ref.append([t.clone() for t in out] + [t.clone() for t in sim.get_state()])
+        sim.close()
+    streams = [torch_mod.cuda.Stream(), torch_mod.cuda.Stream()]
+    sims = []
+    for seed, st in zip((1, 2), streams):
+        with torch_mod.cuda.stream(st):
+            s_ = HipSim(cfg(seed)); s_.reset(); sims.append(s_)
+    outs = [None, None]
+    for _ in range(30):
+        for k in (0, 1):
+            with torch_mod.cuda.stream(streams[k]):
+                outs[k] = sims[k].step(None)
+    got = []
+    for k in (0, 1):
+        with torch_mod.cuda.stream(streams[k]):
+            got.append([t.clone() for t in outs[k]] + [t.clone() for t in sims[k].get_state()])
+        streams[k].synchronize()
+    for r, g_ in zip(ref, got):
+        for a, b in zip(r, g_):
+            assert torch_mod.equal(a, b)
+    for s_ in sims:
+        s_.close()
