@@ -2,6 +2,8 @@
 they are checked against (1) the known answers of SURVEY.md Appendix A, derived from the URDF
 numbers by a COM-Jacobian route, (2) an independent finite-difference Lagrangian
 (tests/lagrange_ref.py) and (3) invariants."""
+import os
+
 import numpy as np
 import pytest
 
@@ -180,3 +182,47 @@ def test_dropped_robot_lands_and_does_not_sink(oracle):
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(qd))
     # the unactuated leg folds and the robot ends up lying on the ground, (almost) at rest
     assert np.abs(qd).max() < 1.0 and q[1] < 0.0
+
+
+def test_oracle_is_clean_under_the_undefined_behaviour_sanitizer(tmp_path):
+    """The oracle is the yardstick of every parity test: a build with -fsanitize=undefined (traps on the first
+    finding) steps every task mode through contacts, randomised resets and truncations without a report.  Runs in
+    a child process, so a trap cannot take the test session down."""
+    import shutil
+    import subprocess
+    import sys
+    import textwrap
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = tmp_path / "libos2r_oracle.so"
+    build = subprocess.run(["gcc", "-O1", "-g", "-fPIC", "-std=c11", "-ffp-contract=off", "-fopenmp", "-fsanitize=undefined",
+                            "-fno-sanitize-recover=undefined", "-I", os.path.join(root, "include"), "-shared", "-o", str(so),
+                            os.path.join(root, "oracle", "os2r_oracle.c"), "-lm", "-lubsan"], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("this gcc has no UBSan runtime: " + build.stderr[-300:])
+    script = textwrap.dedent(f"""
+        import sys, ctypes as C
+        sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        import numpy as np
+        from oracle import oracle_py
+        L = C.CDLL({str(so)!r}); L.orc_tolerance.restype = C.c_double; L.orc_reward.restype = C.c_double
+        L.orc_get_step_count.restype = C.c_uint64; L.orc_set_step_count.argtypes = [C.c_void_p, C.c_uint64]
+        oracle_py._LIB = L
+        from helpers import make_config, MODES
+        from gym_os2r_amd import abi
+        for mode in MODES:
+            reward = "StraightV1" if mode == "simple" else "BalancingV2"
+            cfg, _, _ = make_config(mode, reward, True, reset_mode=abi.RESET_RANDOM, randomize_params=True, num_envs=97,
+                                    contact=True, seed=3, max_episode_steps=11)
+            orc = oracle_py.OracleSim(cfg, threads=4)
+            orc.reset()
+            for _ in range(30):
+                orc.step(None)
+            orc.reset(np.arange(97) % 3 == 0)
+            assert np.isfinite(orc.get_state()[0]).all()
+            orc.close()
+        print("clean")
+    """)
+    run = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0 and "clean" in run.stdout, (run.stdout[-500:], run.stderr[-1500:])
