@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""What the reference's examples/fixed_hip.py does -- random-action episodes of Monopod-balance-v1 behind the
+randomizer wrapper -- with the batch dimension of the HIP runtime: N environments per call instead of one.
+
+  python examples/batched_rollout.py [--envs 4096] [--steps 2000] [--task-mode fixed_hip]
+
+Everything stays on the GPU: the 'policy' below draws its actions there, `env.step` returns device tensors, and
+environments that finish are reset inside the same launch (their last observation is in
+`info['terminal_observation']`), exactly like a SubprocVecEnv worker does it in the reference.
+"""
+import argparse
+import functools
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from gym_os2r_amd import randomizers
+from gym_os2r_amd.common import make_env_from_id
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env-id", default="Monopod-balance-v1")
+    ap.add_argument("--task-mode", default="fixed_hip")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--max-episode-steps", type=int, default=500)
+    args = ap.parse_args()
+
+    make_env = functools.partial(make_env_from_id, env_id=args.env_id, num_envs=args.envs, task_mode=args.task_mode,
+                                 max_episode_steps=args.max_episode_steps)
+    env = randomizers.monopod.MonopodEnvRandomizer(env=make_env)
+    env.seed(42)
+    obs = env.reset()
+    returns = torch.zeros(args.envs, dtype=obs.dtype, device=obs.device)
+    finished = torch.zeros((), dtype=torch.int64, device=obs.device)
+    sum_returns = torch.zeros((), dtype=obs.dtype, device=obs.device)
+    t0 = time.time()
+    for _ in range(args.steps):
+        actions = torch.rand(args.envs, 2, dtype=obs.dtype, device=obs.device) * 2 - 1      # a random policy
+        obs, reward, done, info = env.step(actions)
+        returns += reward
+        # episode bookkeeping without reading anything back: the host never waits for the GPU inside the loop
+        finished += done.sum()
+        sum_returns += torch.where(done, returns, torch.zeros_like(returns)).sum()
+        returns = torch.where(done, torch.zeros_like(returns), returns)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"{args.envs} envs x {args.steps} steps in {dt:.2f} s = {args.envs * args.steps / dt / 1e6:.1f} M env-steps/s; "
+          f"{int(finished)} episodes finished, mean return {float(sum_returns) / max(int(finished), 1):.2f}")
+    r, d = env.get_state_info(obs[0].cpu().numpy(), [actions[0].cpu().numpy(), actions[0].cpu().numpy()])
+    print("get_state_info of env 0:", r, d)
+    env.close()
+
+
+if __name__ == "__main__":
+    main()
