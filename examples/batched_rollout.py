@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--max-episode-steps", type=int, default=500)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one loop iteration (policy, env step, bookkeeping) in a HIP graph and replay it: for small "
+                         "batches the loop is bound by launches, not by the physics")
     args = ap.parse_args()
 
     make_env = functools.partial(make_env_from_id, env_id=args.env_id, num_envs=args.envs, task_mode=args.task_mode,
@@ -38,18 +41,40 @@ def main():
     returns = torch.zeros(args.envs, dtype=obs.dtype, device=obs.device)
     finished = torch.zeros((), dtype=torch.int64, device=obs.device)
     sum_returns = torch.zeros((), dtype=obs.dtype, device=obs.device)
+    sim = env.unwrapped.sim
+    # caller-owned buffers: `step_into` is then one kernel launch and nothing else (what a HIP graph can hold)
+    actions = torch.zeros(args.envs, 2, dtype=obs.dtype, device=obs.device)
+    reward = torch.zeros(args.envs, dtype=obs.dtype, device=obs.device)
+    done_u8 = torch.zeros(args.envs, dtype=torch.uint8, device=obs.device)
+
+    def iteration():
+        actions.copy_(torch.rand(args.envs, 2, dtype=obs.dtype, device=obs.device) * 2 - 1)   # a random policy
+        sim.step_into(actions, obs, reward, done_u8)
+        done = done_u8 != 0
+        returns.add_(reward)
+        # episode bookkeeping without reading anything back: the host never waits for the GPU inside the loop
+        finished.add_(done.sum())
+        sum_returns.add_(torch.where(done, returns, torch.zeros_like(returns)).sum())
+        returns.copy_(torch.where(done, torch.zeros_like(returns), returns))
+
+    graph = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                iteration()                     # warm-up outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            iteration()
+    torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(args.steps):
-        actions = torch.rand(args.envs, 2, dtype=obs.dtype, device=obs.device) * 2 - 1      # a random policy
-        obs, reward, done, info = env.step(actions)
-        returns += reward
-        # episode bookkeeping without reading anything back: the host never waits for the GPU inside the loop
-        finished += done.sum()
-        sum_returns += torch.where(done, returns, torch.zeros_like(returns)).sum()
-        returns = torch.where(done, torch.zeros_like(returns), returns)
+        graph.replay() if graph is not None else iteration()
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(f"{args.envs} envs x {args.steps} steps in {dt:.2f} s = {args.envs * args.steps / dt / 1e6:.1f} M env-steps/s; "
+    print(f"{'HIP graph: ' if graph is not None else ''}{args.envs} envs x {args.steps} steps in {dt:.2f} s = {args.envs * args.steps / dt / 1e6:.1f} M env-steps/s; "
           f"{int(finished)} episodes finished, mean return {float(sum_returns) / max(int(finished), 1):.2f}")
     r, d = env.get_state_info(obs[0].cpu().numpy(), [actions[0].cpu().numpy(), actions[0].cpu().numpy()])
     print("get_state_info of env 0:", r, d)

@@ -324,3 +324,40 @@ def test_handles_on_their_own_streams(torch_mod):
             assert torch_mod.equal(a, b)
     for s_ in sims:
         s_.close()
+
+
+def test_step_can_be_captured_in_a_hip_graph(torch_mod):
+    """A launch-bound loop (a small batch with a policy of tiny kernels around it) can go into a HIP graph:
+    `step_into` with caller-owned buffers is one kernel launch on the capturing stream and nothing else.  A
+    captured step replayed with fresh actions in the static buffer must equal eager stepping, resets included."""
+    from helpers import make_config
+    from gym_os2r_amd.sim import HipSim
+    n = 2048
+    def make():
+        cfg = make_config("fixed_hip", "BalancingV2", True, reset_mode=abi.RESET_RANDOM, randomize_params=True,
+                          num_envs=n, contact=True, seed=5, max_episode_steps=9)[0]
+        s_ = HipSim(cfg); s_.reset(); return s_
+    eager, graphed = make(), make()
+    dt = torch_mod.float64
+    act = torch_mod.zeros(n, 2, dtype=dt, device="cuda")
+    obs = torch_mod.empty(n, eager.D, dtype=dt, device="cuda"); rew = torch_mod.empty(n, dtype=dt, device="cuda")
+    done = torch_mod.empty(n, dtype=torch_mod.uint8, device="cuda"); term = torch_mod.empty_like(obs)
+    gen = torch_mod.Generator(device="cuda"); gen.manual_seed(3)
+    actions = [torch_mod.rand(n, 2, dtype=dt, device="cuda", generator=gen) * 2 - 1 for _ in range(40)]
+    graph = torch_mod.cuda.CUDAGraph()
+    side = torch_mod.cuda.Stream()
+    side.wait_stream(torch_mod.cuda.current_stream())
+    with torch_mod.cuda.stream(side):
+        act.copy_(actions[0]); graphed.step_into(act, obs, rew, done, term)      # step 0 eagerly (warm-up)
+    torch_mod.cuda.current_stream().wait_stream(side)
+    with torch_mod.cuda.graph(graph):
+        graphed.step_into(act, obs, rew, done, term)                            # step 1 is captured (not run) ...
+    ref = [eager.step(a) for a in actions]
+    for k in range(1, 40):
+        act.copy_(actions[k]); graph.replay()                                   # ... and replayed for steps 1..39
+        if k in (1, 8, 9, 20, 39):
+            o, r, d, t = ref[k]
+            assert torch_mod.equal(o, obs) and torch_mod.equal(r, rew) and torch_mod.equal(d, done) and torch_mod.equal(t, term), k
+    for a, b in zip(eager.get_state(), graphed.get_state()):
+        assert torch_mod.equal(a, b)
+    eager.close(); graphed.close()
