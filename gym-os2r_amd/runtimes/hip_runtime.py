@@ -48,6 +48,27 @@ class BatchedInfo(dict):
     def keys(self):
         return list(dict.keys(self)) + list(self._lazy)
 
+    def _materialise(self):
+        for key in list(self._lazy):
+            self[key]
+        return self
+
+    # whole-dict views see every entry: they build the lazy ones first
+    def items(self):
+        return dict.items(self._materialise())
+
+    def values(self):
+        return dict.values(self._materialise())
+
+    def __iter__(self):
+        return dict.__iter__(self._materialise())
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def __repr__(self):
+        return dict.__repr__(self._materialise())
+
     def as_list(self, pose_names):
         n = int(self["done_flags"].shape[0])
         flags = self["done_flags"].cpu().numpy()
