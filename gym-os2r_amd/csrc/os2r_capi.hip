@@ -34,10 +34,13 @@ struct JitEntry {
 static std::mutex g_jit_mutex;
 static std::deque<JitEntry> g_jit;   // entries are never removed: handles keep pointers into it
 
-static const JitEntry* find_jit(const Os2rModel& m, int dtype, int device) {
+// newest registration of this robot that exports kernels for the handle's contact flag (a robot may have been
+// registered once with and once without ground contact: two code objects)
+static const JitEntry* find_jit(const Os2rModel& m, int dtype, int device, bool contact) {
   std::lock_guard<std::mutex> lock(g_jit_mutex);
   for (auto it = g_jit.rbegin(); it != g_jit.rend(); ++it)
-    if (it->dtype == dtype && it->device == device && os2r::same_model(it->model, m)) return &*it;
+    if (it->dtype == dtype && it->device == device && (it->fn[contact][0][0] || it->fn[contact][1][0]) &&
+        os2r::same_model(it->model, m)) return &*it;
   return nullptr;
 }
 
@@ -338,10 +341,10 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   // the randomising reset mode, or a later os2r_set_params (which flips this on)
   s->dr = cfg->task.reset_mode == OS2R_RESET_RANDOM;
   s->model_id = static_model_id(cfg->model);
-  if (s->model_id < 0) s->jit = find_jit(cfg->model, cfg->dtype, cfg->device);
   s->cmask = 0;
   if (cfg->contact)
     for (int k = 0; k < cfg->model.ncand; ++k) s->cmask |= 1u << cfg->model.cand_body[k];
+  if (s->model_id < 0) s->jit = find_jit(cfg->model, cfg->dtype, cfg->device, cfg->contact != 0 && s->cmask != 0u);
   int rc = OS2R_OK;
   auto fail = [&](int code) { g_create_error = s->err; free_all(s); delete s; return code; };
   if (hipSetDevice(cfg->device) != hipSuccess) { s->err = "hipSetDevice failed"; return fail(OS2R_ERR_HIP); }
