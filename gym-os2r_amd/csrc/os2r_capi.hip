@@ -347,6 +347,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   if (s->model_id < 0) s->jit = find_jit(cfg->model, cfg->dtype, cfg->device, cfg->contact != 0 && s->cmask != 0u);
   int rc = OS2R_OK;
   auto fail = [&](int code) { g_create_error = s->err; free_all(s); delete s; return code; };
+  DeviceGuard guard(cfg->device);   // allocate and initialise on the handle's device, then give the caller's back
   if (hipSetDevice(cfg->device) != hipSuccess) { s->err = "hipSetDevice failed"; return fail(OS2R_ERR_HIP); }
   const size_t N = (size_t)cfg->num_envs, n = (size_t)s->nq, e = s->esz;
   if ((rc = dev_alloc(s, &s->q, n * N * e))) return fail(rc);
@@ -391,7 +392,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
 
 int os2r_destroy(Os2rSim* sim) {
   if (!sim) return OS2R_ERR_INVALID;
-  (void)hipSetDevice(sim->cfg.device);
+  DeviceGuard guard(sim->cfg.device);
   (void)hipDeviceSynchronize();
   free_all(sim);
   delete sim;
@@ -491,6 +492,7 @@ int os2r_model_is_compiled_in(const Os2rModel* model) {
 
 int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t device, const char* path) {
   if (!model || !path || (dtype != OS2R_F32 && dtype != OS2R_F64)) { g_create_error = "os2r_register_model_kernels: bad argument"; return OS2R_ERR_INVALID; }
+  DeviceGuard guard(device);
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "os2r_register_model_kernels: hipSetDevice failed"; return OS2R_ERR_HIP; }
   JitEntry e;
   e.model = *model; e.dtype = dtype; e.device = device;
