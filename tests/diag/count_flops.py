@@ -15,7 +15,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -94,7 +94,7 @@ def main():
                 "flops_per_env_step": round(total), "flops_per_physics_iteration": round(sub),
                 "mean_bodies_in_contact": round(cm, 3), "mean_jacobian_columns": round(colm, 3),
                 "stages_per_physics_iteration": {k: round(v, 1) for k, v in stages.items()},
-                "source": "tools/count_flops.py: analytic count of the specification; contact activity measured "
+                "source": "tests/diag/count_flops.py: analytic count of the specification; contact activity measured "
                           "with the CPU oracle on 1024 envs over the bench's 100 warm-up + 1000 timed random-action env-steps"}
         print(name, "flops/env-step", round(total), "contacts", round(cm, 2))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
