@@ -808,6 +808,19 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     V3<T> aw[NQ], jo[NQ];  // world joint axes and joint origins
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      // first chunk of this body's candidate coordinates: requested ahead of the frame arithmetic that covers it
+      constexpr int CHS = 4;
+      T bA[3 * CHS], bB[3 * CHS];
+      auto request = [&](int kk, int kend, T (&d)[3 * CHS]) {
+#pragma unroll
+        for (int j = 0; j < 3 * CHS; ++j) d[j] = (kk + j / 3 < kend) ? mconst->cand_p[kk + j / 3][j % 3] : T(0);   // scalar loads: wave-uniform operands
+      };
+      if constexpr (MD::kStatic) {
+        if ((CMASK >> b) & 1u) {
+          request(md.cand_begin(b), md.cand_begin(b + 1), bA);
+          asm volatile("" ::: "memory");   // issued here, not where the scan starts
+        }
+      }
       const V3<T> r = mk(md.rpos(b, 0), md.rpos(b, 1), md.rpos(b, 2));
       T Rb[9];
       joint_rotation<T>(md, b, sn[b], cs[b], Rb);
@@ -837,6 +850,11 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       // lane of the wave (no candidate can have z < margin then, so W stays 0 exactly)
       const T zc = Rw[6] * md.cand_center(b, 0) + Rw[7] * md.cand_center(b, 1) + Rw[8] * md.cand_center(b, 2) + ow[2];
       const bool near = zc - md.cand_radius(b) < margin;
+      if constexpr (MD::kStatic) {   // the chunk requested ahead is taken here, on either side of the sphere test
+#pragma unroll
+        for (int j = 0; j < 3 * CHS; ++j) asm volatile("" : "+s"(bA[j]));
+        asm volatile("" ::: "memory");
+      }
       if (__ballot(near) != 0ull)
       // Candidate table: wave-shared LDS copy (broadcast reads).  The scan is software
       // pipelined by hand -- two register buffers of 4 candidates, the next chunk is requested
@@ -859,13 +877,15 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         };
         if constexpr (MD::kStatic) {
           const T mo = margin - ow[2];
-          // compile-time candidate counts: straight-line code, the scheduler runs the LDS reads ahead
-          // of their use and there is no loop overhead (branches, buffer copies)
+          // compile-time candidate counts: straight-line code.  Scalar loads return out of order, so the only
+          // wait there is for them is "all arrived": the next chunk is requested right after the current one
+          // has arrived (the asm uses pin that point) and the current chunk's arithmetic covers its flight.
+          auto arrived = [&](T (&d)[3 * CH]) {
 #pragma unroll
-          for (int kk = k0; kk < k1; kk += CH) {
-            T d[3 * CH];
-#pragma unroll
-            for (int j = 0; j < 3 * CH; ++j) d[j] = (kk + j / 3 < k1) ? mconst->cand_p[kk + j / 3][j % 3] : T(0);   // scalar loads: wave-uniform operands
+            for (int j = 0; j < 3 * CH; ++j) asm volatile("" : "+s"(d[j]));
+            asm volatile("" ::: "memory");
+          };
+          auto weigh = [&](const T (&d)[3 * CH], int kk) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
               if (kk + c < k1) {
@@ -875,6 +895,18 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
                 const T wgt = fmax_t(mz, T(0));
                 W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
               }
+            }
+          };
+          static_assert(CH == CHS, "chunk size of the request issued ahead");
+#pragma unroll
+          for (int kk = k0; kk < k1; kk += 2 * CH) {
+            arrived(bA);
+            if (kk + CH < k1) request(kk + CH, k1, bB);
+            weigh(bA, kk);
+            if (kk + CH < k1) {
+              arrived(bB);
+              if (kk + 2 * CH < k1) request(kk + 2 * CH, k1, bA);
+              weigh(bB, kk + CH);
             }
           }
         } else {

@@ -311,6 +311,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   // run-time models scan a wave-shared LDS copy of the candidate table; the compiled-in ones read the
   // (wave-uniform) coordinates through scalar loads, straight into the operands of the scan
   constexpr bool kCandInLds = CONTACT && MD::CMASK != 0u && !MD::kStatic;
+#ifdef OS2R_STAMPS
+  const unsigned long long stamp_entry = __builtin_amdgcn_s_memtime();
+#endif
   __shared__ T tile[lds_words<NQ>() + (kCandInLds ? kCandWords : 0)];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
@@ -362,6 +365,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 
 #ifdef OS2R_STAMPS
   unsigned long long stamps[kStamps] = {}, stamp_prev = __builtin_amdgcn_s_memtime();
+  stamps[10] = stamp_prev - stamp_entry;   // prologue: loads, action, torques
 #endif
   T sn[NQ], cs[NQ];   // sin/cos of the joint angles, carried from one physics iteration to the next
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
@@ -374,10 +378,6 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #endif
     );
   }
-#ifdef OS2R_STAMPS
-  if (A.debug && lane == 0)
-    for (int k = 0; k < kStamps; ++k) A.debug[blockIdx.x * kStamps + k] = stamps[k];
-#endif
   __syncthreads();
 
   bool bad = false;
@@ -387,8 +387,11 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
   T obs[OS2R_MAX_OBS];
   bool dn;
+  OS2R_STAMP(20);
   observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn);
+  OS2R_STAMP(21);
   const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
+  OS2R_STAMP(22);
   int steps = A.steps[e] + 1;
   const bool trunc = ts->max_episode_steps > 0 && steps >= ts->max_episode_steps;
   const uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
@@ -410,6 +413,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     }
   }
   if (A.obs) store_obs_tile<T>(A.obs, obs, D, e0, A.N, lane, tile);
+  OS2R_STAMP(23);
 
   if (valid) {
 #pragma unroll
@@ -430,6 +434,11 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     if (A.reward) A.reward[e] = rew;
     if (A.done) A.done[e] = flag;
   }
+#ifdef OS2R_STAMPS
+  stamps[11] = __builtin_amdgcn_s_memtime() - stamp_prev;   // the state and flag stores, issued
+  if (A.debug && lane == 0)
+    for (int k = 0; k < kStamps; ++k) A.debug[blockIdx.x * kStamps + k] = stamps[k];
+#endif
 }
 
 // fp32 state fits two waves per SIMD (<= 256 registers, 17.7 KB LDS): the second wave hides what a lone

@@ -17,9 +17,9 @@ _lib.LIB_PATH = os.path.join(ROOT, "gym-os2r_amd", "libos2r_stamps.so")
 import bench
 
 PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y)", "contact: forward kinematics",
-          "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "-", "-",
+          "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "prologue (once per env-step)", "epilogue: state stores (once per env-step)",
           "  dyn: body velocities", "  dyn: inward body 4", "  dyn: inward body 3", "  dyn: inward body 2", "  dyn: inward body 1",
-          "  dyn: inward body 0", "-", "  Minv: inward", "-", "-", "-", "-"]
+          "  dyn: inward body 0", "-", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)"]
 NS = 24   # kStamps in os2r_device.hpp
 
 
@@ -43,13 +43,13 @@ def main():
         per_wave = buf.cpu().numpy().reshape(nwg, NS)
         acc += per_wave.mean(axis=0)
         tot_w = per_wave.sum(axis=1)
-        spread = (tot_w.min(), tot_w.mean(), tot_w.max())
+        spread = (tot_w.min(), tot_w.mean(), tot_w.max(), tot_w.std(), np.percentile(tot_w, 50), np.percentile(tot_w, 99))
     acc /= 20
     ms = sim.bench_steps(200) / 200
     print(f"stamp build: {ms * 1e3:.1f} us per env-step launch -> {ms * 1e6 / acc.sum():.3f} ns per tick of the stamped part")
     tot = acc.sum()
     print(f"workload {A.workload}: {tot:.0f} ticks per env-step per wave ({tot / cfg.substeps:.0f} per physics iteration)")
-    print(f"per-wave ticks of the last step: min {spread[0]:.0f} mean {spread[1]:.0f} max {spread[2]:.0f} (max/mean {spread[2] / spread[1]:.3f})")
+    print(f"per-wave ticks of the last step: min {spread[0]:.0f} mean {spread[1]:.0f} max {spread[2]:.0f} (max/mean {spread[2] / spread[1]:.3f}; std {spread[3]:.0f}, median {spread[4]:.0f}, p99 {spread[5]:.0f})")
     for name, v in zip(PHASES, acc):
         print(f"  {name:42s} {v / cfg.substeps:9.0f} ticks/iter  {100 * v / tot:5.1f} %")
 
