@@ -229,6 +229,11 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
   a.steps = s->steps; a.episode = s->episode; a.pose = s->pose; a.violations = s->violations;
   a.debug = s->debug;
+  a.layout_kinds = 0; a.layout_srcs = 0; a.layout_dim = s->cfg.task.obs_dim;
+  for (int d = 0; d < s->cfg.task.obs_dim && d < OS2R_MAX_OBS; ++d) {
+    a.layout_kinds |= (unsigned long long)(s->cfg.task.obs_kind[d] & 15) << (4 * d);
+    a.layout_srcs |= (unsigned long long)(s->cfg.task.obs_src[d] & 15) << (4 * d);
+  }
   return a;
 }
 

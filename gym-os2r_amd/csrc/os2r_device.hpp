@@ -132,6 +132,10 @@ struct StepArgs {
   T* __restrict__ term_obs;       // [N][D] or null
   const uint8_t* __restrict__ reset_mask;  // reset kernel only
   unsigned long long* __restrict__ debug;  // diagnostic stamp builds only (else null)
+  // host side of the launch only: the observation layout of the handle's task, 4 bits per slot (slot 0 lowest),
+  // compared with the layouts that exist as compile-time variants of the step kernel
+  unsigned long long layout_kinds, layout_srcs;
+  int layout_dim;
 };
 
 // ----------------------------------------------------------------------------------------

@@ -18,14 +18,50 @@ namespace os2r {
 
 using T = OS2R_REAL;
 
+// Observation layouts of the reference's task modes on this unit's robot (tasks/monopod.py:105-200 evaluated
+// on models/config/default/settings.yaml; {kind OS2R_OBS_*, source dof} per slot): the step kernel exists with
+// each of them folded in (contact on, default sweep counts); any other layout runs the generic one.
+#define OS2R_LAYOUT(NAME, D, ...)                                                                   \
+  struct NAME##_t { static constexpr int k[D][2] = {__VA_ARGS__}; };                                 \
+  constexpr unsigned long long NAME##_pack(int col) {                                                \
+    int v[D] = {};                                                                                   \
+    for (int i = 0; i < D; ++i) v[i] = NAME##_t::k[i][col];                                          \
+    return pack_layout(v, D);                                                                        \
+  }                                                                                                  \
+  using NAME = StLayout<NAME##_pack(0), NAME##_pack(1), D>;
+#if OS2R_UNIT == 0   // monopod: free_hip
+OS2R_LAYOUT(LayA, 10, {0, 3}, {1, 4}, {0, 1}, {1, 0}, {0, 2}, {2, 3}, {2, 4}, {2, 1}, {2, 0}, {2, 2})
+#elif OS2R_UNIT == 1  // monopod-fixed_hip: fixed_hip, fixed_hip_simple (the default env id)
+OS2R_LAYOUT(LayA, 8, {0, 2}, {1, 3}, {0, 1}, {1, 0}, {2, 2}, {2, 3}, {2, 1}, {2, 0})
+OS2R_LAYOUT(LayB, 5, {0, 2}, {1, 3}, {0, 1}, {2, 2}, {2, 3})
+#elif OS2R_UNIT == 2  // monopod-fixed: fixed
+OS2R_LAYOUT(LayA, 6, {0, 1}, {1, 2}, {0, 0}, {2, 1}, {2, 2}, {2, 0})
+#elif OS2R_UNIT == 3  // monopod-simple: simple
+OS2R_LAYOUT(LayA, 4, {0, 0}, {1, 1}, {2, 0}, {2, 1})
+#endif
+
+template <typename LAY>
+static bool layout_is(const StepArgs<T>& a) {
+  return a.layout_dim == LAY::kDim && a.layout_kinds == LAY::kKinds && a.layout_srcs == LAY::kSrcs;
+}
+
 template <typename MD, bool CONTACT, bool DR>
 static void launch_step(const StepArgs<T>& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave)), block(kWave);
   // the compiled-in robots also exist with the default sweep counts as compile-time loop bounds
-  if (MD::kStatic && a.pgs_iters == kStdPgsIters && a.pgs_normal_iters == kStdPgsNormalIters)
+  if (MD::kStatic && a.pgs_iters == kStdPgsIters && a.pgs_normal_iters == kStdPgsNormalIters) {
+#if OS2R_UNIT < 10
+    if constexpr (CONTACT) {
+      if (layout_is<LayA>(a)) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA>), grid, block, 0, s, a); return; }
+#if OS2R_UNIT == 1
+      if (layout_is<LayB>(a)) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB>), grid, block, 0, s, a); return; }
+#endif
+    }
+#endif
     hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic>), grid, block, 0, s, a);
-  else
+  } else {
     hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, false>), grid, block, 0, s, a);
+  }
 }
 
 template <typename R, int UNIT>

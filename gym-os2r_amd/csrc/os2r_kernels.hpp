@@ -61,34 +61,67 @@ __device__ __forceinline__ T wrap_pi(T x) {
 }
 
 // value before the affine / tanh map, and the observation itself (tasks/monopod.py:238-272)
-template <typename T, int NQ>
+// Observation layout: which quantity feeds which slot and through which map.  It is data of the task
+// (RtLayout: read from the task struct), and for the layouts of the reference's task modes on the compiled-in
+// robots also a compile-time variant (StLayout): the slot loop below then folds into straight-line code --
+// no per-slot dispatch on the kind, no select chains over the joints (they were ~500 cycles per slot for a
+// wave that owns its SIMD: the whole observation 10.7 k cycles per env-step against 3 k of arithmetic).
+struct RtLayout {
+  static constexpr bool kStatic = false;
+  static constexpr int kDim = 0;
+  static constexpr int kind(int) { return 0; }
+  static constexpr int src(int) { return 0; }
+};
+template <unsigned long long KINDS, unsigned long long SRCS, int DIM>
+struct StLayout {
+  static constexpr bool kStatic = true;
+  static constexpr unsigned long long kKinds = KINDS, kSrcs = SRCS;
+  static constexpr int kDim = DIM;
+  static constexpr int kind(int d) { return (int)((KINDS >> (4 * d)) & 15ull); }
+  static constexpr int src(int d) { return (int)((SRCS >> (4 * d)) & 15ull); }
+};
+constexpr unsigned long long pack_layout(const int* v, int n) {
+  unsigned long long r = 0;
+  for (int i = 0; i < n; ++i) r |= (unsigned long long)(v[i] & 15) << (4 * i);
+  return r;
+}
+
+template <typename T, int NQ, typename LAY = RtLayout>
 __device__ __forceinline__ void observe(TaskPtr<T> ts, const T (&q)[NQ], const T (&qd)[NQ],
                                         T h1a, T h1b, T (&obs)[OS2R_MAX_OBS], bool& done) {
 #pragma clang fp contract(off)
   done = false;
-  int D = ts->obs_dim;
-  asm volatile("" : "+s"(D));   // one copy in a register: not re-fetched (and waited for) slot after slot
-  // The layout of the observation is data (one kernel serves every task mode).  Its constants are fetched
-  // half the slots at a time, ahead of the slots' arithmetic: left to the point of use, every slot waits for
-  // five scalar loads in turn, which a lone wave cannot hide (most of 12 k cycles per env-step, measured).
-  constexpr int H = OS2R_MAX_OBS / 2;
+  int D = LAY::kStatic ? LAY::kDim : ts->obs_dim;
+  if constexpr (!LAY::kStatic) asm volatile("" : "+s"(D));   // one copy in a register: not re-fetched (and waited for) slot after slot
+  // The slots' constants are fetched four slots at a time, ahead of the slots' arithmetic: left to the
+  // point of use, every slot waits for five scalar loads in turn, which a lone wave cannot hide.
+  constexpr int H = 4;
+  static_assert(OS2R_MAX_OBS % H == 0, "whole batches");
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int batch = 0; batch < OS2R_MAX_OBS / H; ++batch) {
+    if (LAY::kStatic && batch * H >= LAY::kDim) {
+#pragma unroll
+      for (int k = 0; k < H; ++k) obs[batch * H + k] = T(0);
+      continue;
+    }
     int kind_[H], src_[H];
     T lo_[H], hi_[H], dlo_[H], dhi_[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) {
-      const int d = half * H + k;
-      kind_[k] = ts->obs_kind[d]; src_[k] = ts->obs_src[d];
+      const int d = batch * H + k;
+      kind_[k] = LAY::kStatic ? LAY::kind(d) : ts->obs_kind[d];
+      src_[k] = LAY::kStatic ? LAY::src(d) : ts->obs_src[d];
       lo_[k] = ts->obs_low[d]; hi_[k] = ts->obs_high[d];
       dlo_[k] = ts->done_lo[d]; dhi_[k] = ts->done_hi[d];
     }
 #pragma unroll
-    for (int k = 0; k < H; ++k)   // used here: the loads are not sunk into the branches below
-      asm volatile("" : "+s"(kind_[k]), "+s"(src_[k]), "+s"(lo_[k]), "+s"(hi_[k]), "+s"(dlo_[k]), "+s"(dhi_[k]));
+    for (int k = 0; k < H; ++k) {   // used here: the loads are not sunk into the branches below
+      if constexpr (!LAY::kStatic) asm volatile("" : "+s"(kind_[k]), "+s"(src_[k]));
+      asm volatile("" : "+s"(lo_[k]), "+s"(hi_[k]), "+s"(dlo_[k]), "+s"(dhi_[k]));
+    }
 #pragma unroll
     for (int k = 0; k < H; ++k) {
-      const int d = half * H + k;
+      const int d = batch * H + k;
       if (d >= D) { obs[d] = T(0); continue; }
       const int kind = kind_[k], s = src_[k];
       T x = T(0);
@@ -354,7 +387,7 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 // One env-step of this wave's 64 environments: the body of every step kernel (the templated ones below and
 // the model-specialised ones of os2r_jit_unit.hip).  STD_SWEEPS: the solver's sweep counts are the default
 // ones and known at compile time (the launcher checks the handle's configuration).
-template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false>
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false, typename LAY = RtLayout>
 __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
   // run-time models scan a wave-shared LDS copy of the candidate table; the compiled-in ones read the
@@ -437,7 +470,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   T obs[OS2R_MAX_OBS];
   bool dn;
   OS2R_STAMP(20);
-  observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn);
+  observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn);
   OS2R_STAMP(21);
   const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
   OS2R_STAMP(22);
@@ -458,7 +491,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
       epi += 1;
       steps = 0;
       bool dn2;
-      observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn2);
+      observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn2);
     }
   }
   if (A.obs) store_obs_tile<T>(A.obs, obs, D, e0, A.N, lane, tile);
@@ -495,9 +528,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #define OS2R_STEP_KERNEL_ATTRS(REAL) \
   __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
 
-template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS>
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS, typename LAY = RtLayout>
 __global__ OS2R_STEP_KERNEL_ATTRS(T) void step_kernel(const StepArgs<T> A) {
-  step_body<T, MD, CONTACT, DR, STD_SWEEPS>(A);
+  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY>(A);
 }
 
 // ----------------------------------------------------------------------------------------
