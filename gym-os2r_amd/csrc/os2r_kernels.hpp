@@ -477,7 +477,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   int steps = A.steps[e] + 1;
   const bool trunc = ts->max_episode_steps > 0 && steps >= ts->max_episode_steps;
   const uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
-  const int D = ts->obs_dim;
+  const int D = LAY::kStatic ? LAY::kDim : ts->obs_dim;
 
   if (A.term_obs) store_obs_tile<T>(A.term_obs, obs, D, e0, A.N, lane, tile);
 
