@@ -690,8 +690,21 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   T vs[NQ];  // predicted velocity v* = qd + dt*qdd
   {
     V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, -par.gravity());
+    // the inward pass's hand-over (u, U, 1/D) of joint i + 1 is requested while joint i is worked on: a lone
+    // wave sits out every LDS round trip that is requested where it is needed
+    T hu[2], hd[2];
+    V3<T> hua[2], hul[2];
+    auto request = [&](int i, int b) { hu[b] = L(kU + i); hua[b] = ldv(kUa, i); hul[b] = ldv(kUl, i); hd[b] = L(kDi + i); };
+    auto arrived = [&](int b) {
+      asm volatile("" : "+v"(hu[b]), "+v"(hd[b]), "+v"(hua[b].x), "+v"(hua[b].y), "+v"(hua[b].z), "+v"(hul[b].x), "+v"(hul[b].y), "+v"(hul[b].z));
+      asm volatile("" ::: "memory");
+    };
+    request(0, 0);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
+      const int b = i & 1;
+      arrived(b);
+      if (i + 1 < NQ) request(i + 1, b ^ 1);
       const int ax = md.axis(i);
       const V3<T> r = mk(md.rpos(i, 0), md.rpos(i, 1), md.rpos(i, 2));
       V3<T> sq = mk<T>(0, 0, 0);
@@ -702,7 +715,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       const V3<T> pl_ = rtmul(Ri, al + cross(aa, r));
       aa = pa_ + cross(wv[i], sq);
       al = pl_ + cross(vv[i], sq);
-      const T qdd = (L(kU + i) - dot(ldv(kUa, i), aa) - dot(ldv(kUl, i), al)) * L(kDi + i);
+      const T qdd = (hu[b] - dot(hua[b], aa) - dot(hul[b], al)) * hd[b];
       add_comp(aa, ax, qdd);
       vs[i] = qd[i] + dt * qdd;
     }
