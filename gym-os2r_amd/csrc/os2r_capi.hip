@@ -29,19 +29,39 @@ struct JitEntry {
   int dtype = 0, device = 0;
   hipModule_t module = nullptr;
   hipFunction_t fn[2][2][2] = {};   // [contact][per-env parameters][default sweep counts compiled in]
+  // optional: contact + default sweep counts + the observation layout below folded in (os2r_jit_step_c1_d*_l)
+  hipFunction_t fn_layout[2] = {};
+  unsigned long long layout_kinds = 0, layout_srcs = 0;
+  int layout_dim = -1;
 };
+
+static void task_layout(const Os2rTaskSpec& t, unsigned long long& kinds, unsigned long long& srcs, int& dim) {
+  kinds = 0; srcs = 0; dim = t.obs_dim;
+  for (int d = 0; d < t.obs_dim && d < OS2R_MAX_OBS; ++d) {
+    kinds |= (unsigned long long)(t.obs_kind[d] & 15) << (4 * d);
+    srcs |= (unsigned long long)(t.obs_src[d] & 15) << (4 * d);
+  }
+}
 
 static std::mutex g_jit_mutex;
 static std::deque<JitEntry> g_jit;   // entries are never removed: handles keep pointers into it
 
 // newest registration of this robot that exports kernels for the handle's contact flag (a robot may have been
 // registered once with and once without ground contact: two code objects)
-static const JitEntry* find_jit(const Os2rModel& m, int dtype, int device, bool contact) {
+static const JitEntry* find_jit(const Os2rModel& m, int dtype, int device, bool contact, const Os2rTaskSpec& task) {
+  unsigned long long kinds, srcs;
+  int dim;
+  task_layout(task, kinds, srcs, dim);
   std::lock_guard<std::mutex> lock(g_jit_mutex);
+  const JitEntry* any = nullptr;
   for (auto it = g_jit.rbegin(); it != g_jit.rend(); ++it)
     if (it->dtype == dtype && it->device == device && (it->fn[contact][0][0] || it->fn[contact][1][0]) &&
-        os2r::same_model(it->model, m)) return &*it;
-  return nullptr;
+        os2r::same_model(it->model, m)) {
+      // a code object built for this handle's observation layout is preferred over a newer one built for another
+      if (contact && it->layout_dim == dim && it->layout_kinds == kinds && it->layout_srcs == srcs) return &*it;
+      if (!any) any = &*it;
+    }
+  return any;
 }
 
 namespace {
@@ -229,11 +249,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
   a.steps = s->steps; a.episode = s->episode; a.pose = s->pose; a.violations = s->violations;
   a.debug = s->debug;
-  a.layout_kinds = 0; a.layout_srcs = 0; a.layout_dim = s->cfg.task.obs_dim;
-  for (int d = 0; d < s->cfg.task.obs_dim && d < OS2R_MAX_OBS; ++d) {
-    a.layout_kinds |= (unsigned long long)(s->cfg.task.obs_kind[d] & 15) << (4 * d);
-    a.layout_srcs |= (unsigned long long)(s->cfg.task.obs_src[d] & 15) << (4 * d);
-  }
+  task_layout(s->cfg.task, a.layout_kinds, a.layout_srcs, a.layout_dim);
   return a;
 }
 
@@ -253,8 +269,11 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
   const bool contact = s->cfg.contact != 0 && s->cmask != 0u;
   const bool std_sweeps = s->cfg.pgs_iters == kStdPgsIters && s->cfg.pgs_normal_iters == kStdPgsNormalIters;
-  const hipFunction_t jit_fn = !s->jit ? nullptr
+  hipFunction_t jit_fn = !s->jit ? nullptr
       : (std_sweeps && s->jit->fn[contact][s->dr][1]) ? s->jit->fn[contact][s->dr][1] : s->jit->fn[contact][s->dr][0];
+  if (s->jit && contact && std_sweeps && s->jit->fn_layout[s->dr] && s->jit->layout_dim == a.layout_dim &&
+      s->jit->layout_kinds == a.layout_kinds && s->jit->layout_srcs == a.layout_srcs)
+    jit_fn = s->jit->fn_layout[s->dr];
   if (jit_fn) {
     // the robot's own code object: same StepArgs, passed as the kernel-argument buffer
     StepArgs<T> args = a;
@@ -349,7 +368,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   s->cmask = 0;
   if (cfg->contact)
     for (int k = 0; k < cfg->model.ncand; ++k) s->cmask |= 1u << cfg->model.cand_body[k];
-  if (s->model_id < 0) s->jit = find_jit(cfg->model, cfg->dtype, cfg->device, cfg->contact != 0 && s->cmask != 0u);
+  if (s->model_id < 0) s->jit = find_jit(cfg->model, cfg->dtype, cfg->device, cfg->contact != 0 && s->cmask != 0u, cfg->task);
   int rc = OS2R_OK;
   auto fail = [&](int code) { g_create_error = s->err; free_all(s); delete s; return code; };
   DeviceGuard guard(cfg->device);   // allocate and initialise on the handle's device, then give the caller's back
@@ -511,6 +530,17 @@ int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t d
         if (hipModuleGetFunction(&e.fn[c][d][v], e.module, (name + (v ? "_s" : "")).c_str()) == hipSuccess) ++found;
         else e.fn[c][d][v] = nullptr;
     }
+  hipDeviceptr_t lay = nullptr;
+  size_t lay_bytes = 0;
+  if (hipModuleGetGlobal(&lay, &lay_bytes, e.module, "os2r_jit_layout") == hipSuccess && lay_bytes >= 3 * sizeof(unsigned long long)) {
+    unsigned long long v[3] = {};
+    if (hipMemcpy(v, lay, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
+      bool both = true;
+      for (int d = 0; d < 2; ++d)
+        if (hipModuleGetFunction(&e.fn_layout[d], e.module, (std::string("os2r_jit_step_c1_d") + char('0' + d) + "_l").c_str()) != hipSuccess) { e.fn_layout[d] = nullptr; both = false; }
+      if (both) { e.layout_kinds = v[0]; e.layout_srcs = v[1]; e.layout_dim = (int)v[2]; }
+    }
+  }
   (void)hipGetLastError();   // a missing variant is not an error
   if (!found) { (void)hipModuleUnload(e.module); g_create_error = std::string(path) + " exports no os2r_jit_step_* kernel"; return OS2R_ERR_INVALID; }
   std::lock_guard<std::mutex> lock(g_jit_mutex);

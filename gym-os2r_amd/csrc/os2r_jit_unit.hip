@@ -36,6 +36,19 @@ using JitModel = StModel<JitReal, 100>;
 #if OS2R_JIT_CONTACT
 OS2R_JIT_KERNEL(os2r_jit_step_c1_d0, true, false)
 OS2R_JIT_KERNEL(os2r_jit_step_c1_d1, true, true)
+// NAME_l: additionally the observation layout of the task the code object was built for (StLayout), announced
+// in os2r_jit_layout = {kinds, sources, slots}; handles with another layout use the kernels above
+#ifdef OS2R_JIT_LAYOUT_DIM
+extern "C" __device__ __attribute__((used)) const unsigned long long os2r_jit_layout[3] = {
+    OS2R_JIT_LAYOUT_KINDS, OS2R_JIT_LAYOUT_SRCS, OS2R_JIT_LAYOUT_DIM};
+namespace os2r { using JitLayout = StLayout<OS2R_JIT_LAYOUT_KINDS, OS2R_JIT_LAYOUT_SRCS, OS2R_JIT_LAYOUT_DIM>; }
+#define OS2R_JIT_LAYOUT_KERNEL(NAME, DR)                                                          \
+  extern "C" __global__ OS2R_STEP_KERNEL_ATTRS(OS2R_REAL) void NAME(const os2r::StepArgs<os2r::JitReal> A) { \
+    os2r::step_body<os2r::JitReal, os2r::JitModel, true, DR, true, os2r::JitLayout>(A);             \
+  }
+OS2R_JIT_LAYOUT_KERNEL(os2r_jit_step_c1_d0_l, false)
+OS2R_JIT_LAYOUT_KERNEL(os2r_jit_step_c1_d1_l, true)
+#endif
 #else
 OS2R_JIT_KERNEL(os2r_jit_step_c0_d0, false, false)
 OS2R_JIT_KERNEL(os2r_jit_step_c0_d1, false, true)
