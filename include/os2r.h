@@ -209,7 +209,11 @@ int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward
  * uses it for every handle on `device` whose dtype matches and whose Os2rModel equals `model`
  * bit for bit (gravity_z excluded: it is a per-handle value).  Variants the code object does not
  * export (os2r_jit_step_c{0,1}_d{0,1}: contact off/on, per-env parameters off/on) fall back to the
- * generic kernels.  Errors: os2r_last_error(NULL).                                          */
+ * generic kernels.  A code object may also export os2r_jit_step_c1_d{0,1}_l together with the data
+ * symbol os2r_jit_layout = {kinds, sources, slots} (4 bits per observation slot): the contact
+ * kernels with that observation layout folded in; handles whose task has exactly that layout use
+ * them, and of several code objects of one robot the one built for the handle's layout is taken.
+ * Errors: os2r_last_error(NULL).                                                            */
 int os2r_model_is_compiled_in(const Os2rModel* model);
 int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t device,
                                 const char* code_object_path);
