@@ -189,6 +189,24 @@ struct StModel {
   __device__ __forceinline__ constexpr T cand(int k, int j) const { return (T)Tb::cand_p[k][j]; }
   __device__ __forceinline__ constexpr T cand_center(int b, int j) const { return (T)Tb::cand_center[b][j]; }
   __device__ __forceinline__ constexpr T cand_radius(int b) const { return (T)Tb::cand_radius[b]; }
+  // Candidate points of a link often share a coordinate (the two faces of a plate, a rim at constant height):
+  // number of runs of equal values of coordinate `a` among the link's candidates, and the coordinate with the
+  // fewest runs -- the scan evaluates that coordinate's terms once per run instead of once per point.
+  static constexpr int cand_runs(int b, int a) {
+    int n = 0;
+    for (int k = Tb::cand_begin[b]; k < Tb::cand_begin[b + 1]; ++k)
+      if (k == Tb::cand_begin[b] || Tb::cand_p[k][a] != Tb::cand_p[k - 1][a]) ++n;
+    return n;
+  }
+  static constexpr int cand_group_axis(int b) {
+    int best = 0;
+    for (int a = 1; a < 3; ++a)
+      if (cand_runs(b, a) < cand_runs(b, best)) best = a;
+    return best;
+  }
+  static constexpr bool cand_starts_run(int b, int k, int a) {
+    return k == Tb::cand_begin[b] || Tb::cand_p[k][a] != Tb::cand_p[k - 1][a];
+  }
 };
 
 // ----------------------------------------------------------------------------------------
@@ -902,15 +920,25 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
             for (int j = 0; j < 3 * CH; ++j) asm volatile("" : "+s"(d[j]));
             asm volatile("" ::: "memory");
           };
+          // margin - z with the frame origin folded into the constant term (one add less), and the terms of the
+          // coordinate the link's points share in runs (ga; a compile-time property of the table) taken once per
+          // run: its product enters the height through `base`, its moment is the run's weight times the value
+          const int ga = MD::cand_group_axis(b), a1 = (ga + 1) % 3, a2 = (ga + 2) % 3;   // folded: b is an unrolled loop index
+          T S[3] = {T(0), T(0), T(0)};
+          T Wg = T(0), pg = T(0), base = mo;
           auto weigh = [&](const T (&d)[3 * CH], int kk) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
               if (kk + c < k1) {
-                const T px = d[3 * c], py = d[3 * c + 1], pz = d[3 * c + 2];
-                // margin - z with the frame origin folded into the constant term: one add less
-                const T mz = __builtin_fma(-Rw[6], px, __builtin_fma(-Rw[7], py, __builtin_fma(-Rw[8], pz, mo)));
+                if (MD::cand_starts_run(b, kk + c, ga)) {
+                  W += Wg; S[ga] = __builtin_fma(pg, Wg, S[ga]);
+                  Wg = T(0); pg = d[3 * c + ga];
+                  base = __builtin_fma(-Rw[6 + ga], pg, mo);
+                }
+                const T p1 = d[3 * c + a1], p2 = d[3 * c + a2];
+                const T mz = __builtin_fma(-Rw[6 + a1], p1, __builtin_fma(-Rw[6 + a2], p2, base));
                 const T wgt = fmax_t(mz, T(0));
-                W += wgt; sx += wgt * px; sy += wgt * py; sz += wgt * pz;
+                Wg += wgt; S[a1] = __builtin_fma(wgt, p1, S[a1]); S[a2] = __builtin_fma(wgt, p2, S[a2]);
               }
             }
           };
@@ -926,6 +954,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
               weigh(bB, kk + CH);
             }
           }
+          W += Wg; S[ga] = __builtin_fma(pg, Wg, S[ga]);
+          sx = S[0]; sy = S[1]; sz = S[2];
         } else {
         T bufA[3 * CH], bufB[3 * CH];
         int k = k0;
