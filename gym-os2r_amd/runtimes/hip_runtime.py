@@ -114,6 +114,7 @@ class HipRuntime:
         self._randomize_params = False
         self._sim = None
         self._bad_flag, self._bad_event, self._bad_pending, self._bad_slot = None, None, [False, False], 0
+        self._bad_seen = 0        # running count of clamped actions already reported
         cfg = getattr(self.task, "cfg", None) or SettingsConfig()
         self.model = dict(get_model(cfg.get_config(f"task_modes/{self.task.task_mode}/model")))
         self.pose_names = list(cfg.get_config("/resets").keys())
@@ -152,6 +153,7 @@ class HipRuntime:
                                     contact=o["contact"], pgs_iters=o["pgs_iters"],
                                     pgs_normal_iters=o["pgs_normal_iters"], auto_reset=o["auto_reset"])
             self._sim = HipSim(cfg, device=o["device"])
+            self._bad_seen, self._bad_pending = 0, [False, False]     # a new handle counts from zero
         return self._sim
 
     def reset(self, mask=None):
@@ -184,13 +186,14 @@ class HipRuntime:
         device_actions = isinstance(actions, torch.Tensor) and actions.is_cuda
         obs, rew, flags, term = sim.step(a, want_terminal=True)
         if device_actions:
-            # the kernel clamps out-of-range actions and counts them; the count travels to pinned
-            # host memory behind this step and is looked at in the next call
+            # the kernel clamps out-of-range actions and counts them; the running count (never cleared: one
+            # small copy per step instead of a copy and a memset) travels to pinned host memory behind this
+            # step and is compared with the count already reported two calls later
             if self._bad_flag is None:
                 self._bad_flag = torch.zeros(2, dtype=torch.int32).pin_memory()
                 self._bad_event = [torch.cuda.Event(), torch.cuda.Event()]
             k = self._bad_slot
-            sim.action_violations_into(self._bad_flag[k:k + 1], clear=True)
+            sim.action_violations_into(self._bad_flag[k:k + 1], clear=False)
             self._bad_event[k].record(torch.cuda.current_stream(sim.device))
             self._bad_pending[k] = True
             self._bad_slot = 1 - k
@@ -211,12 +214,17 @@ class HipRuntime:
     def _raise_if_bad_actions(self, drain: bool = False):
         """Look at the verdicts that are due: the one of two calls ago (its kernel has finished while the
         last one runs, so nothing waits), or all of them when draining in reset()/close()."""
-        for k in ((0, 1) if drain else (self._bad_slot,)):
+        for k in ((self._bad_slot, 1 - self._bad_slot) if drain else (self._bad_slot,)):   # oldest first
             if self._bad_pending[k]:
                 self._bad_event[k].synchronize()
                 self._bad_pending[k] = False
-                if int(self._bad_flag[k]) != 0:
-                    self._bad_pending = [False, False]
+                if int(self._bad_flag[k]) != self._bad_seen:
+                    # one report per burst: the verdict of the step behind this one is taken in as well
+                    o = 1 - k
+                    if self._bad_pending[o]:
+                        self._bad_event[o].synchronize()
+                        self._bad_pending[o] = False
+                    self._bad_seen = max(int(self._bad_flag[k]), int(self._bad_flag[o]))
                     raise AssertionError("invalid: actions of an earlier step() left the action space [-1, 1] "
                                          "(they were clamped, as the backend clamps the torque)")
 
