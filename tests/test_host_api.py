@@ -274,3 +274,25 @@ def test_jit_builds_a_code_object_for_a_custom_robot(monkeypatch):
     assert jit.code_object_path(ms, abi.F32, True) != path and jit.code_object_path(ms, abi.F64, False) != path
     ms.mass[0] = np.nextafter(ms.mass[0], 1.0)
     assert jit.code_object_path(ms, abi.F64, True) != path           # any constant of the robot is part of the key
+
+
+def test_jit_code_object_with_the_task_layout_folded_in(monkeypatch):
+    """With the layout of a task (`jit.task_layout`) the code object also exports the contact kernels that have
+    the observation layout folded in, and the data symbol that announces which layout that is."""
+    from conftest import KERNEL_CACHE
+    from helpers import make_config, perturbed_model
+    from gym_os2r_amd import jit
+    if jit.hipcc_path() is None:
+        pytest.skip("no hipcc on this machine")
+    monkeypatch.setenv("OS2R_KERNEL_CACHE", KERNEL_CACHE)
+    model = perturbed_model("fixed_hip", np.random.default_rng(79))       # the robot of the GPU test: cached for it
+    cfg, _, _ = make_config("fixed_hip_simple", "BalancingV1", True, num_envs=8, contact=True, model_overrides=model)
+    lay = jit.task_layout(cfg.task)
+    assert lay == (0x22010, 0x32132, 5)                                    # kinds / source dofs, slot 0 lowest
+    path = jit.build(cfg.model, abi.F64, True, layout=lay)
+    blob = open(path, "rb").read()
+    assert b"os2r_jit_step_c1_d0_l" in blob and b"os2r_jit_step_c1_d1_l" in blob and b"os2r_jit_layout" in blob
+    assert path != jit.code_object_path(cfg.model, abi.F64, True, None)
+    assert jit.code_object_path(cfg.model, abi.F64, False, lay) == jit.code_object_path(cfg.model, abi.F64, False, None)
+    cfg.task.obs_kind[0] = 99                                              # does not fit four bits: no folded layout
+    assert jit.task_layout(cfg.task) is None
