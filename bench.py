@@ -11,9 +11,17 @@ free-boom balancing task (task_mode 'free_hip', BalancingV1) with ground contact
 randomisation (link mass, joint damping/friction, ground friction, gravity), randomised resets.
 Envs shard embarrassingly over ranks (contiguous ranges, no data-path collective): weak scaling.
 
+The workload is rolled into its stationary regime before anything is timed (--preroll steps, outside
+the timed region and independent of --warmup): freshly reset robots hang 1-5 cm above the ground and the
+first few hundred env-steps (free fall, first impacts, collapse) are lighter than the steady state the
+rollout then stays in, so a short window right after the reset would measure a phase, not the path.
+
 Rank 0 prints ONE JSON line: the contract keys plus
-  roofline      HBM view of the step kernel (algorithmic bytes / HIP-event kernel time)
-  roofline_valu fp64 vector-ALU view of the same kernel (the resource that actually binds)
+  roofline      HBM view of the step kernel (algorithmic bytes / HIP-event kernel time of this run)
+  roofline_valu fp64 vector-ALU view of the same kernel (the resource that actually binds): the flops the
+                kernel executed in THIS run's timed window -- its work counted by replaying the window from a
+                checkpoint with the counting variant of the kernel (same arithmetic, bit for bit), priced by
+                profiles/flop_model.json (per-unit flops fitted to rocprofv3 PMC counts) -- over the kernel time
   cpu_baseline  the CPU oracle (scalar fp64 port) timed on this box's host cores, N=1 only
 """
 import argparse
@@ -60,7 +68,7 @@ def build_config(args, rank, world):
     n = args.envs_per_gpu
     cfg = abi.config_struct(model, spec, num_envs=n, env_offset=rank * n, seed=args.seed,
                             dtype=abi.F64 if args.dtype == "f64" else abi.F32, contact=contact,
-                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters)
+                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters, pgs_tol=args.pgs_tol)
     return cfg, model, spec
 
 
@@ -111,13 +119,51 @@ def cpu_baseline(args, cfg):
             "single_core": {"value": steps1 * 128 / dt1, "sample": f"{steps1} env-steps x 128 envs, {dt1:.1f} s"}}
 
 
-def load_traffic():
-    """HBM traffic per launch from separate rocprofv3 --pmc passes (profiles/), if recorded."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+def load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
         with open(p) as f:
             return json.load(f)
     return None
+
+
+def counted_flops(sim, ck, steps, dr, workload):
+    """Replay the timed window from its checkpoint with the counting kernel variant: the work the timed
+    launches did (the rollout is deterministic), priced with profiles/flop_model.json.  -> dict or None."""
+    from gym_os2r_amd import abi
+    from gym_os2r_amd.sim import Os2rError
+    model = (load_json("flop_model.json") or {}).get(f"{workload}_f64")
+    try:
+        sim.set_state(ck["q"], ck["qd"])
+        sim.set_action_history(0, ck["hist0"]); sim.set_action_history(1, ck["hist1"])
+        if dr:                                        # (restoring parameters would switch a nominal handle to per-env ones)
+            for f, v in ck["params"].items():
+                sim.set_params(f, v)
+        sim.set_episode_info(ck["steps"], ck["episode"], ck["pose"])
+        sim.step_count = ck["step_count"]
+        sim.count_work(True)
+        sim.bench_steps(steps)
+        c = sim.work_counters()
+        sim.count_work(False)
+    except Os2rError:
+        sim.count_work(False)
+        return None                                   # no counting variant for this configuration
+    waves = (sim.N + 63) // 64
+    wi = max(c["wave_iterations"], 1)
+    out = {"activity": {"scanned_bodies_per_wave_iteration": c["scanned_bodies"] / wi,
+                        "row_bodies_per_wave_iteration": c["row_bodies"] / wi,
+                        "phase2_sweeps_per_wave_iteration": c["sweeps"] / wi,
+                        "bodies_in_contact_per_env": c["lane_contacts"] / (wi * 64.0),
+                        "live_envs_per_sweep": c["live_lane_sweeps"] / max(c["sweeps"], 1),
+                        "full_sincos_per_wave_iteration": c["full_sincos"] / wi},
+           "counters": c}
+    if model:
+        k = model["flops_per_unit"]
+        total = (k["launch_wave"] * waves * steps + k["wave_iteration"] * c["wave_iterations"] + k["scanned_body"] * c["scanned_bodies"]
+                 + k["row_body"] * c["row_bodies"] + k["body_sweep"] * c["body_sweeps"] + k["sweep"] * c["sweeps"])
+        out["flops_per_launch"] = total / steps
+        out["model"] = model.get("source")
+    return out
 
 
 def main():
@@ -125,12 +171,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--preroll", type=int, default=1000,
+                    help="env-steps run before warm-up, outside the timed region, so that the window measures the "
+                         "stationary regime of the rollout whatever --warmup and --steps are (0: start at the reset)")
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pgs-iters", type=int, default=20)
     ap.add_argument("--pgs-normal-iters", type=int, default=3)
+    ap.add_argument("--pgs-tol", type=float, default=1e-24, help="stopping tolerance of the solver's sweeps [J] (0: fixed counts)")
+    ap.add_argument("--no-count", action="store_true", help="skip the counting replay of the timed window")
     ap.add_argument("--cpu-envs", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +234,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sim.bench_steps(max(args.warmup, 1)) if args.warmup > 0 else None
+    if args.preroll > 0:
+        sim.bench_steps(args.preroll)
+    if args.warmup > 0:
+        sim.bench_steps(args.warmup)
+    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64"
+    ck = sim.checkpoint() if count else None          # start of the timed window, for the counting replay
     barrier()
     t0 = time.perf_counter()
     if not args.gather_obs:
@@ -214,7 +270,7 @@ def main():
         per_launch_s = kernel_ms * 1e-3 / args.steps
         bytes_launch = algorithmic_bytes_per_env_step(cfg, esz) * args.envs_per_gpu
         achieved = bytes_launch / per_launch_s / 1e9
-        traffic = load_traffic()
+        traffic = load_json("traffic.json")
         out = {
             "metric": "env-steps/sec (aggregate) monopod balance task",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,37 +279,34 @@ def main():
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}",
                        "envs_per_gpu": args.envs_per_gpu, "total_envs": total_envs, "task_mode": WORKLOADS[args.workload][0],
                        "substeps": int(cfg.substeps), "dt": float(cfg.dt), "pgs_sweeps": [int(cfg.pgs_normal_iters), int(cfg.pgs_iters)],
+                       "pgs_tol": float(cfg.pgs_tol), "preroll_steps": args.preroll,
                        "contact": bool(cfg.contact), "domain_randomisation": WORKLOADS[args.workload][3],
                        "actions": "U(-1,1) Philox on device",
                        "sharding": f"envs x{world}, " + ("obs/reward/done gathered to rank 0 every step" if args.gather_obs else "no step-path collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
+                         "traffic_source": None if traffic is None else
+                         "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " + str(traffic.get("source")) + "; not measured by this run)",
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "note": "ALU-bound path: see roofline_valu"},
         }
-        flops = None
-        fp = os.path.join(ROOT, "profiles", "flops.json")
-        if os.path.exists(fp):
-            with open(fp) as f:
-                flops = json.load(f).get(f"{args.workload}_{args.dtype}")
-        if flops:
-            tf = flops["flops_per_env_step"] * args.envs_per_gpu / per_launch_s / 1e12
-            peak = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
+        peak = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
+        cf = counted_flops(sim, ck, args.steps, WORKLOADS[args.workload][3], args.workload) if count else None
+        if cf and "flops_per_launch" in cf:
+            tf = cf["flops_per_launch"] / per_launch_s / 1e12
             out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": tf / peak, "flops_per_env_step": flops["flops_per_env_step"],
-                                    "source": flops.get("source")}
-            # what the kernel actually executes (it reaches the specification's result with fewer operations:
-            # whitened rows, factor of the inverse mass matrix straight from the ABA): PMC-counted, C4 f64 only
-            ip = os.path.join(ROOT, "profiles", "r01_issue_breakdown.json")
-            if os.path.exists(ip) and args.workload == "C4" and args.dtype == "f64":
-                with open(ip) as f:
-                    counted = json.load(f).get("fp64_flops_per_env_step_counted")
-                if counted:
-                    tfe = counted * args.envs_per_gpu / per_launch_s / 1e12
-                    out["roofline_valu"].update({"executed_flops_per_env_step": counted, "achieved_executed": tfe,
-                                                 "frac_executed": tfe / peak})
+                                    "frac": tf / peak, "flops_per_env_step": cf["flops_per_launch"] / args.envs_per_gpu,
+                                    "flops_source": "work of this run's timed window (counting replay from a checkpoint) x " + str(cf["model"]),
+                                    "activity": cf["activity"]}
+        elif cf:
+            out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,
+                                    "flops_source": "profiles/flop_model.json missing: work counted, not priced", "activity": cf["activity"]}
+        spec = (load_json("flops.json") or {}).get(f"{args.workload}_{args.dtype}")
+        if spec and "roofline_valu" in out:
+            # the specification's straightforward operation count (tests/diag/count_flops.py), for reference only
+            out["roofline_valu"]["specification_flops_per_env_step"] = spec["flops_per_env_step"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Mapping
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_DOF = 5
 MAX_CAND = 192
 MAX_OBS = 12
@@ -110,6 +110,7 @@ class Os2rConfig(C.Structure):
         ("erp", C.c_double),
         ("max_erv", C.c_double),
         ("contact_margin", C.c_double),
+        ("pgs_tol", C.c_double),
         ("model", Os2rModel),
         ("task", Os2rTaskSpec),
     ]
@@ -208,7 +209,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
                   dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 3,
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
-                  contact_margin: float = 1e-3) -> Os2rConfig:
+                  contact_margin: float = 1e-3, pgs_tol: float = 1e-24) -> Os2rConfig:
     c = Os2rConfig()
     c.abi_version = ABI_VERSION
     c.dtype = int(dtype)
@@ -225,6 +226,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     c.erp = float(erp)
     c.max_erv = float(max_erv)
     c.contact_margin = float(contact_margin)
+    c.pgs_tol = float(pgs_tol)
     c.model = model_struct(model)
     c.task = task_struct(task)
     return c

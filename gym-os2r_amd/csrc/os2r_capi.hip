@@ -101,7 +101,8 @@ struct SimBase {
   uint8_t* pose = nullptr;
   unsigned int* violations = nullptr;
   // scratch outputs for os2r_bench_steps
-  void *b_obs = nullptr, *b_rew = nullptr;
+  void *b_obs = nullptr, *b_rew = nullptr, *b_term = nullptr;
+  unsigned long long* counters = nullptr;   // caller-owned work-counter buffer (os2r_set_work_counters)
   uint8_t* b_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned long long* debug = nullptr;  // diagnostic stamp builds only
@@ -225,6 +226,7 @@ int validate(const Os2rConfig* c, std::string& why) {
   if (c->pgs_iters < 0 || c->pgs_iters > 10000) { why = "pgs_iters out of range"; return 1; }
   if (!(c->contact_margin >= 0.0)) { why = "contact_margin must be >= 0"; return 1; }
   if (c->pgs_normal_iters < 0 || c->pgs_normal_iters > 10000) { why = "pgs_normal_iters out of range"; return 1; }
+  if (!(c->pgs_tol >= 0.0)) { why = "pgs_tol must be >= 0"; return 1; }
   return 0;
 }
 
@@ -244,6 +246,8 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.auto_reset = s->cfg.auto_reset;
   a.dt = (T)s->cfg.dt; a.erp = (T)s->cfg.erp; a.max_erv = (T)s->cfg.max_erv; a.margin = (T)s->cfg.contact_margin;
   a.gravity_z = (T)s->cfg.model.gravity_z;
+  a.pgs_tol = (T)s->cfg.pgs_tol;
+  a.counters = s->counters;
   a.q = (T*)s->q; a.qd = (T*)s->qd; a.hist = (T*)s->hist;
   a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
@@ -274,6 +278,7 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
   if (s->jit && contact && std_sweeps && s->jit->fn_layout[s->dr] && s->jit->layout_dim == a.layout_dim &&
       s->jit->layout_kinds == a.layout_kinds && s->jit->layout_srcs == a.layout_srcs)
     jit_fn = s->jit->fn_layout[s->dr];
+  if (a.counters && jit_fn) { s->err = "no counting variant in run-time code objects"; return OS2R_ERR_INVALID; }
   if (jit_fn) {
     // the robot's own code object: same StepArgs, passed as the kernel-argument buffer
     StepArgs<T> args = a;
@@ -281,7 +286,10 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
     const unsigned grid = (unsigned)((a.N + kWave - 1) / kWave);
     HIP_TRY(s, hipModuleLaunchKernel(jit_fn, grid, 1, 1, kWave, 1, 1, 0, st, nullptr, extra));
-  } else if (Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st) != 0) { s->err = "no step kernel for this chain length / contact mask"; return OS2R_ERR_INVALID; }
+  } else if (Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st) != 0) {
+    s->err = a.counters ? "no counting variant of the step kernel for this configuration" : "no step kernel for this chain length / contact mask";
+    return OS2R_ERR_INVALID;
+  }
   HIP_TRY(s, hipGetLastError());
   s->step_count += 1;
   return OS2R_OK;
@@ -388,6 +396,7 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   if ((rc = dev_alloc(s, (void**)&s->violations, 4))) return fail(rc);
   if ((rc = dev_alloc(s, &s->b_obs, (size_t)s->D * N * e))) return fail(rc);
   if ((rc = dev_alloc(s, &s->b_rew, N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->b_term, (size_t)s->D * N * e))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->b_done, N))) return fail(rc);
   if (cfg->dtype == OS2R_F64) {
     DevModel<double> hm; DevTask<double> ht;
@@ -574,12 +583,18 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) 
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(sim, hipEventRecord(sim->ev0, st));
   for (int k = 0; k < nsteps; ++k) {
-    int rc = os2r_step(sim, nullptr, sim->b_obs, sim->b_rew, sim->b_done, nullptr, stream);
+    int rc = os2r_step(sim, nullptr, sim->b_obs, sim->b_rew, sim->b_done, sim->b_term, stream);
     if (rc) return rc;
   }
   HIP_TRY(sim, hipEventRecord(sim->ev1, st));
   HIP_TRY(sim, hipEventSynchronize(sim->ev1));
   HIP_TRY(sim, hipEventElapsedTime(elapsed_ms, sim->ev0, sim->ev1));
+  return OS2R_OK;
+}
+
+int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev) {
+  if (!sim) return OS2R_ERR_INVALID;
+  sim->counters = (unsigned long long*)counters_dev;
   return OS2R_OK;
 }
 

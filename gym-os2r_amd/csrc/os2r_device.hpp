@@ -37,6 +37,22 @@ namespace os2r {
 constexpr int kWave = 64;
 // the sweep counts of the default configuration: kernels built for them have compile-time loop bounds (+2 %)
 constexpr int kStdPgsIters = 20, kStdPgsNormalIters = 3;
+// Phase-2 sweeps run in groups of kPgsGroup; the last sweep of a group measures the energy it moved
+// (sum over the rows of |residual * impulse change|, the decrease of the QP objective up to a factor <= 2) and an
+// environment whose measure is within pgs_tol stops sweeping.  Per lane: what an
+// environment computes does not depend on the company it keeps in its wave.
+constexpr int kPgsGroup = 4;
+
+// Work done by one wave in one physics iteration, for the counting kernel variants (wave-uniform values).
+struct WorkCounts {
+  unsigned scanned = 0;       // bodies whose candidate scan ran
+  unsigned row_bodies = 0;    // bodies whose contact rows were set up (some lane of the wave touches)
+  unsigned body_sweeps = 0;   // phase-2 sweeps executed x bodies they covered
+  unsigned sweeps = 0;        // phase-2 sweeps executed (some lane still live)
+  unsigned lane_contacts = 0; // (lane, body) pairs in contact
+  unsigned live_lane_sweeps = 0;  // phase-2 sweeps x lanes still live in them
+  unsigned full_sincos = 0;   // 1 if some lane evaluated sin/cos in full in this iteration
+};
 
 // ----------------------------------------------------------------------------------------
 // uniform (per-handle) device data
@@ -111,6 +127,7 @@ struct StepArgs {
   int pgs_normal_iters;
   int auto_reset;
   T dt, erp, max_erv, margin, gravity_z;
+  T pgs_tol;   // an environment stops sweeping once a checked sweep moved less energy than this (0: exact fixed points only)
   // state, SoA
   T* __restrict__ q;         // [nq][N]
   T* __restrict__ qd;        // [nq][N]
@@ -132,6 +149,7 @@ struct StepArgs {
   T* __restrict__ term_obs;       // [N][D] or null
   const uint8_t* __restrict__ reset_mask;  // reset kernel only
   unsigned long long* __restrict__ debug;  // diagnostic stamp builds only (else null)
+  unsigned long long* __restrict__ counters;  // work counters of the counting kernel variants (os2r_set_work_counters), else null
   // host side of the launch only: the observation layout of the handle's task, 4 bits per slot (slot 0 lowest),
   // compared with the layouts that exist as compile-time variants of the step kernel
   unsigned long long layout_kinds, layout_srcs;
@@ -498,12 +516,12 @@ __device__ __forceinline__ bool for_body(int b, F&& f) {
   }
 }
 
-template <typename T, typename MD, bool CONTACT, bool DR>
+template <typename T, typename MD, bool CONTACT, bool DR, bool COUNT = false>
 __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& par,
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T (&sn)[MD::NQ], T (&cs)[MD::NQ], bool first_iteration,
                                         T tau_hip, T tau_knee, T dt, T erp,
-                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T* __restrict__ lds,
-                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst
+                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T pgs_tol, T* __restrict__ lds,
+                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst, WorkCounts& wc
 #ifdef OS2R_STAMPS
                                         , unsigned long long (&stamps)[kStamps], unsigned long long& stamp_prev
 #endif
@@ -525,6 +543,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int i = 0; i < NQ; ++i) { ok = ok && sincos_in_range(q[i]); small = small && fabs_t(dt * qd[i]) < T(0.01); }
     // The choice is made per lane (divergent branches; a wave whose lanes agree, the usual case, executes one
     // side only): what a lane computes must not depend on who shares its wave.
+    if constexpr (COUNT) wc.full_sincos += __ballot(!small) != 0ull ? 1u : 0u;
     if (small) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
@@ -890,6 +909,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         for (int j = 0; j < 3 * CHS; ++j) asm volatile("" : "+s"(bA[j]));
         asm volatile("" ::: "memory");
       }
+      if constexpr (COUNT) wc.scanned += __ballot(near) != 0ull ? 1u : 0u;
       if (__ballot(near) != 0ull)
       // Candidate table: wave-shared LDS copy (broadcast reads).  The scan is software
       // pipelined by hand -- two register buffers of 4 candidates, the next chunk is requested
@@ -982,6 +1002,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       OS2R_STAMP(5);
       act[b] = W > T(0);
       wave_act[b] = __ballot(act[b]) != 0ull;
+      if constexpr (COUNT) { wc.row_bodies += wave_act[b] ? 1u : 0u; wc.lane_contacts += (unsigned)__popcll(__ballot(act[b])); }
       if (wave_act[b]) {
         // the factor rows this body needs are requested first; the Jacobian below covers the LDS trip
         T lcb[NQ][NQ];
@@ -1053,7 +1074,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // them from LDS inside the sweep left every row waiting a full round trip, which at one wave per SIMD
   // nothing hides (that was half of the solver's time); parking them in LDS between set-up and sweeps
   // cost a wait too (+1.2 % without it).
-  auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper) {
+  T moved = T(0);   // energy moved by the measuring sweep of a group: sum over the rows of |residual * impulse change|
+  auto contact_row = [&](int b, int row, T target, T rd, T& l, T lo, T hi, bool upper, bool measure) {
     // Explicit fused operations, in source order: with contraction left to the compiler a sum of two products
     // (`g0*y0 + g1*y1` when the target is zero) has two fused forms, and which one it picks differs between the
     // specialised and the general sweep code -- a lane's result would depend on its company in the wave.
@@ -1067,11 +1089,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     if (upper) lam = lam > hi ? hi : lam;
     const T dl = lam - l;
     l = lam;
+    if (measure) moved = fma_t(fabs_t(res), fabs_t(dl), moved);
 #pragma unroll
     for (int k = 0; k < NQ; ++k)
       if (k <= b) y[k] = fma_t(g[k], dl, y[k]);
   };
-  auto joint_rows = [&]() {
+  auto joint_rows = [&](bool measure) {
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       // joint Coulomb friction row: J = e_j, G = row j of Lc, d = Minv[j][j]
@@ -1084,6 +1107,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       lam = lam > fb[j] ? fb[j] : lam;
       const T dl = lam - lf[j];
       lf[j] = lam;
+      if (measure) moved = fma_t(fabs_t(res), fabs_t(dl), moved);
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
         if (k <= j) y[k] = fma_t(Lc[j][k], dl, y[k]);
@@ -1102,23 +1126,64 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
+      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false, false);
     }
-    joint_rows();
+    joint_rows(false);
   };
-  auto sweep = [&](auto coupled, auto first) {
+  auto sweep = [&](auto coupled, auto first, auto measure_) {
+    constexpr bool measure = decltype(measure_)::value;
     constexpr int kFirst = decltype(first)::value;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false);
+      contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false, measure);
       if (decltype(coupled)::value) limfix[b] = mub[b] * ln[b];   // the coupled pyramid, experiments only
       const T lim = limfix[b];
-      contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true);
-      contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true);
+      contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true, measure);
+      contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true, measure);
     }
-    joint_rows();
+    joint_rows(measure);
+  };
+  // Phase 2 in groups of kPgsGroup sweeps.  The last sweep of a group measures what it moved; an environment
+  // that moved no more than pgs_tol is done and sits out the remaining groups (a divergent branch: the wave
+  // skips a group once none of its lanes is live, and a lane's result does not depend on the other lanes).
+  // With pgs_tol == 0 only an exact fixed point stops an environment, which changes nothing: every further
+  // sweep would reproduce the state bit for bit.
+  auto grouped_sweeps = [&](auto coupled, auto first) {
+    constexpr int kFirst = decltype(first)::value;
+    bool live = true;
+    auto group = [&](int n, bool check) {
+      if constexpr (COUNT) {
+        const unsigned long long lv = __ballot(live && n > 0);   // the wave runs the group if any of its lanes is live
+        if (lv != 0ull) {
+          unsigned nb = 0;
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            if ((CMASK >> b) & 1u) nb += (kFirst >= 0 ? b >= kFirst : wave_act[b]) ? 1u : 0u;
+          wc.sweeps += (unsigned)n; wc.body_sweeps += (unsigned)n * nb;
+          wc.live_lane_sweeps += (unsigned)n * (unsigned)__popcll(lv);
+        }
+      }
+      if (live && n > 0) {
+        if (n == kPgsGroup) {
+#pragma unroll
+          for (int k = 0; k + 1 < kPgsGroup; ++k) sweep(coupled, first, std::false_type{});
+        } else {
+          for (int k = 0; k + 1 < n; ++k) sweep(coupled, first, std::false_type{});
+        }
+        if (check) {
+          moved = T(0);
+          sweep(coupled, first, std::true_type{});
+          live = moved > pgs_tol;
+        } else {
+          sweep(coupled, first, std::false_type{});
+        }
+      }
+    };
+    int it = 0;
+    for (; it + kPgsGroup < pgs_iters; it += kPgsGroup) group(kPgsGroup, true);   // a check after the last sweep would decide nothing
+    group(pgs_iters - it, false);
   };
   int first_act = NB;
   bool is_suffix = true;
@@ -1132,13 +1197,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_STAMP(7);
 #pragma unroll
     for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
-#pragma unroll 4
-    for (int it = 0; it < pgs_iters; ++it) sweep(std::false_type{}, first);
+    grouped_sweeps(std::false_type{}, first);
   };
   if (!fixed_box) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) limfix[b] = 0;
-    for (int it = 0; it < pgs_iters; ++it) sweep(std::true_type{}, std::integral_constant<int, -1>{});
+    grouped_sweeps(std::true_type{}, std::integral_constant<int, -1>{});
   } else if (!(is_suffix && first_act < NB && for_body<0, NB, CMASK>(first_act, solve_fixed_box))) {
     solve_fixed_box(std::integral_constant<int, -1>{});
   }

@@ -45,23 +45,43 @@ static bool layout_is(const StepArgs<T>& a) {
   return a.layout_dim == LAY::kDim && a.layout_kinds == LAY::kKinds && a.layout_srcs == LAY::kSrcs;
 }
 
+// fp64 only: the counting variants (os2r_set_work_counters) of the layout kernels
+[[maybe_unused]] constexpr bool kHaveCounting = sizeof(T) == 8;
+
 template <typename MD, bool CONTACT, bool DR>
-static void launch_step(const StepArgs<T>& a, hipStream_t s) {
+static int launch_step(const StepArgs<T>& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave)), block(kWave);
   // the compiled-in robots also exist with the default sweep counts as compile-time loop bounds
   if (MD::kStatic && a.pgs_iters == kStdPgsIters && a.pgs_normal_iters == kStdPgsNormalIters) {
 #if OS2R_UNIT < 10
     if constexpr (CONTACT) {
-      if (layout_is<LayA>(a)) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA>), grid, block, 0, s, a); return; }
+      if (layout_is<LayA>(a)) {
+        if constexpr (kHaveCounting) {
+          if (a.counters) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA, true>), grid, block, 0, s, a); return 0; }
+        }
+        if (a.counters) return 1;
+        hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA>), grid, block, 0, s, a);
+        return 0;
+      }
 #if OS2R_UNIT == 1
-      if (layout_is<LayB>(a)) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB>), grid, block, 0, s, a); return; }
+      if (layout_is<LayB>(a)) {
+        if constexpr (kHaveCounting) {
+          if (a.counters) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB, true>), grid, block, 0, s, a); return 0; }
+        }
+        if (a.counters) return 1;
+        hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB>), grid, block, 0, s, a);
+        return 0;
+      }
 #endif
     }
 #endif
+    if (a.counters) return 1;
     hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic>), grid, block, 0, s, a);
   } else {
+    if (a.counters) return 1;
     hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, false>), grid, block, 0, s, a);
   }
+  return 0;
 }
 
 template <typename R, int UNIT>
@@ -78,9 +98,8 @@ using MD = RtModel<T, OS2R_UNIT - 10>;
 template <>
 int step_unit<T, OS2R_UNIT>(bool contact, bool dr, const StepArgs<T>& a, hipStream_t s) {
   if (MD::CMASK == 0u) contact = false;   // a chain that cannot reach the ground
-  if (contact) { dr ? launch_step<MD, true, true>(a, s) : launch_step<MD, true, false>(a, s); }
-  else { dr ? launch_step<MD, false, true>(a, s) : launch_step<MD, false, false>(a, s); }
-  return 0;
+  if (contact) return dr ? launch_step<MD, true, true>(a, s) : launch_step<MD, true, false>(a, s);
+  return dr ? launch_step<MD, false, true>(a, s) : launch_step<MD, false, false>(a, s);
 }
 
 #if OS2R_UNIT >= 10

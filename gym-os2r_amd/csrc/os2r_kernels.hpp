@@ -387,7 +387,10 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 // One env-step of this wave's 64 environments: the body of every step kernel (the templated ones below and
 // the model-specialised ones of os2r_jit_unit.hip).  STD_SWEEPS: the solver's sweep counts are the default
 // ones and known at compile time (the launcher checks the handle's configuration).
-template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false, typename LAY = RtLayout>
+// COUNT: the counting variant (os2r_set_work_counters): same arithmetic, and the wave's work of the launch is added to
+// A.counters[0..kWorkCounters) by one lane at the end.
+constexpr int kWorkCounters = OS2R_NUM_WORK_COUNTERS;
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false, typename LAY = RtLayout, bool COUNT = false>
 __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
   // run-time models scan a wave-shared LDS copy of the candidate table; the compiled-in ones read the
@@ -450,17 +453,26 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   stamps[10] = stamp_prev - stamp_entry;   // prologue: loads, action, torques
 #endif
   T sn[NQ], cs[NQ];   // sin/cos of the joint angles, carried from one physics iteration to the next
+  WorkCounts wc;
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR>(md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
-                                STD_SWEEPS ? kStdPgsIters : A.pgs_iters, STD_SWEEPS ? kStdPgsNormalIters : A.pgs_normal_iters,
-                                tile, cand_lds, as_const(A.model)
+    substep<T, MD, CONTACT, DR, COUNT>(md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
+                                       STD_SWEEPS ? kStdPgsIters : A.pgs_iters, STD_SWEEPS ? kStdPgsNormalIters : A.pgs_normal_iters,
+                                       A.pgs_tol, tile, cand_lds, as_const(A.model), wc
 #ifdef OS2R_STAMPS
-                                , stamps, stamp_prev
+                                       , stamps, stamp_prev
 #endif
     );
   }
   __syncthreads();
+  if constexpr (COUNT) {
+    if (A.counters && lane == 0) {
+      const unsigned long long v[kWorkCounters] = {(unsigned long long)A.substeps, wc.scanned, wc.row_bodies, wc.body_sweeps,
+                                                    wc.sweeps, wc.lane_contacts, wc.live_lane_sweeps, wc.full_sincos};
+#pragma unroll
+      for (int k = 0; k < kWorkCounters; ++k) atomicAdd(A.counters + k, v[k]);
+    }
+  }
 
   bool bad = false;
 #pragma unroll
@@ -528,9 +540,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #define OS2R_STEP_KERNEL_ATTRS(REAL) \
   __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
 
-template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS, typename LAY = RtLayout>
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS, typename LAY = RtLayout, bool COUNT = false>
 __global__ OS2R_STEP_KERNEL_ATTRS(T) void step_kernel(const StepArgs<T> A) {
-  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY>(A);
+  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY, COUNT>(A);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -88,6 +88,9 @@ class _PybindLib:
         ms_ref._obj.value = ms
         return rc
 
+    def os2r_set_work_counters(self, h, buf):
+        return self.m.set_work_counters(self._a(h), self._a(buf))
+
     def os2r_last_error(self, h):
         return self.m.last_error(self._a(h)).encode()
 
@@ -176,6 +179,23 @@ class HipSim:
         ms = C.c_float()
         self._check(self._lib.os2r_bench_steps(self._h, int(nsteps), self._stream(), C.byref(ms)), "os2r_bench_steps")
         return float(ms.value)
+
+    WORK_COUNTERS = ("wave_iterations", "scanned_bodies", "row_bodies", "body_sweeps", "sweeps", "lane_contacts",
+                     "live_lane_sweeps", "full_sincos")
+
+    def count_work(self, on: bool = True):
+        """Switch the counting variant of the step kernel on (include/os2r.h: os2r_set_work_counters) or off.
+        While on, `work_counters()` returns what the launches since have added up."""
+        self._counters = torch.zeros(len(self.WORK_COUNTERS), dtype=torch.int64, device=self.device) if on else None
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.os2r_set_work_counters(self._h, _ptr(self._counters)), "os2r_set_work_counters")
+
+    def work_counters(self, clear: bool = True) -> dict:
+        torch.cuda.current_stream(self.device).synchronize()
+        v = self._counters.cpu().tolist()
+        if clear:
+            self._counters.zero_()
+        return dict(zip(self.WORK_COUNTERS, v))
 
     # -- state ------------------------------------------------------------------------------
     def get_state(self):

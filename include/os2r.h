@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OS2R_ABI_VERSION 1
+#define OS2R_ABI_VERSION 2
 
 #define OS2R_MAX_DOF 5      /* yaw, pitch, boom_connector, hip, knee                       */
 #define OS2R_MAX_CAND 192   /* ground-contact candidate points of one model                */
@@ -159,6 +159,8 @@ typedef struct Os2rConfig {
   double erp;              /* contact error-reduction parameter                              */
   double max_erv;          /* cap on the error-reduction velocity [m/s]                      */
   double contact_margin;   /* candidates closer than this to the ground join the contact [m] */
+  double pgs_tol;          /* an environment stops sweeping once a checked sweep (every 4th) moved */
+                           /*   no more energy than this [J]; 0: exact fixed points only          */
   Os2rModel model;
   Os2rTaskSpec task;
 } Os2rConfig;
@@ -254,9 +256,21 @@ int os2r_set_step_count(Os2rSim* sim, uint64_t value);
 
 /* Timing helper for benchmarks: runs `nsteps` os2r_step launches with on-device
  * random actions on the given stream, bracketed by HIP events recorded on that
- * stream; returns the elapsed GPU time in milliseconds. Outputs go to internal
- * scratch buffers.                                                               */
+ * stream; returns the elapsed GPU time in milliseconds. Every output of os2r_step
+ * (observation, reward, done, terminal observation) goes to internal scratch
+ * buffers: the timed launch is the one a gym-level env.step makes.               */
 int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
+
+/* Work counters (measurement support, bench.py's roofline): while a buffer of OS2R_NUM_WORK_COUNTERS uint64 (device
+ * memory, zeroed by the caller) is set, os2r_step launches the counting variant of the step kernel -- the same
+ * arithmetic, bit for bit -- whose waves add the work they did to it: [0] wave x physics iterations, [1] bodies whose
+ * candidate scan ran, [2] bodies whose contact rows were set up, [3] phase-2 sweeps x bodies they covered,
+ * [4] phase-2 sweeps executed, [5] (environment, body) contacts, [6] phase-2 sweeps x environments still live in
+ * them, [7] wave x iterations that evaluated sin/cos in full.  Counting variants exist for the compiled-in robots
+ * with ground contact, the default sweep counts and a reference task layout (OS2R_ERR_INVALID otherwise).
+ * NULL switches counting off.                                                                                   */
+#define OS2R_NUM_WORK_COUNTERS 8
+int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
 
 const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */
 

@@ -117,16 +117,47 @@ def contact_points(model_struct, rw, ow, margin=0.0):
     return active.astype(bool), pw, -depth
 
 
-def substep(cfg, q, qd, tau2, mass_scale=None, damping=None, friction=None, mu=None, gravity_z=None):
+CONTACT_CENTROID, CONTACT_PER_VERTEX = 0, 1   # os2r_oracle.h: the specification / the oracle-only comparison model
+
+
+def substep(cfg, q, qd, tau2, mass_scale=None, damping=None, friction=None, mu=None, gravity_z=None,
+            contact_model=CONTACT_CENTROID):
     q = np.array(q, dtype=np.float64)
     qd = np.array(qd, dtype=np.float64)
     t = np.ascontiguousarray(tau2, dtype=np.float64)
     arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64)
             for a in (mass_scale, damping, friction, mu)]
     g = cfg.model.gravity_z if gravity_z is None else gravity_z
-    lib().orc_substep(C.byref(cfg), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]),
-                      C.c_double(g), _p(q), _p(qd), _p(t))
+    lib().orc_substep_model(C.byref(cfg), C.c_int(contact_model), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]),
+                            C.c_double(g), _p(q), _p(qd), _p(t))
     return q, qd
+
+
+def contact_problem(cfg, q, qd, tau2, mass_scale=None, damping=None, friction=None, mu=None, gravity_z=None,
+                    contact_model=CONTACT_CENTROID, max_rows=3 * 192 + 5):
+    """The boxed LCP of one physics iteration at (q, qd) and the oracle's solution of it with cfg's sweep
+    counts (os2r_oracle.c: orc_contact_problem).  -> dict of numpy arrays."""
+    n = cfg.model.nq
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    qd = np.ascontiguousarray(qd, dtype=np.float64)
+    t = np.ascontiguousarray(tau2, dtype=np.float64)
+    arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+            for a in (mass_scale, damping, friction, mu)]
+    g = cfg.model.gravity_z if gravity_z is None else gravity_z
+    vstar, minv, v_out = np.zeros(n), np.zeros((n, n)), np.zeros(n)
+    J, target = np.zeros((max_rows, n)), np.zeros(max_rows)
+    kind, nrow, body = (np.zeros(max_rows, dtype=np.int32) for _ in range(3))
+    bound, box, lam, point = np.zeros(max_rows), np.zeros(max_rows), np.zeros(max_rows), np.zeros((max_rows, 3))
+    f = lib().orc_contact_problem
+    f.restype = C.c_int
+    nr = f(C.byref(cfg), C.c_int(contact_model), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]), _p(arrs[3]), C.c_double(g),
+           _p(q), _p(qd), _p(t), C.c_int(max_rows), _p(vstar), _p(minv), _p(J), _p(target), _p(kind), _p(nrow),
+           _p(body), _p(bound), _p(box), _p(lam), _p(point), _p(v_out))
+    if nr < 0:
+        raise RuntimeError("orc_contact_problem: more rows than max_rows")
+    return {"nr": nr, "vstar": vstar, "minv": minv, "J": J[:nr], "target": target[:nr], "kind": kind[:nr],
+            "normal_row": nrow[:nr], "body": body[:nr], "bound": bound[:nr], "box": box[:nr], "lambda": lam[:nr],
+            "point": point[:nr], "v": v_out}
 
 
 class OracleSim:
@@ -142,6 +173,10 @@ class OracleSim:
         if rc != 0:
             raise RuntimeError(f"orc_create failed: {rc}")
         lib().orc_set_threads(self._h, int(threads))
+
+    def set_contact_model(self, model: int):
+        """CONTACT_CENTROID (the specification, default) or CONTACT_PER_VERTEX (comparison model)."""
+        lib().orc_set_contact_model(self._h, int(model))
 
     def close(self):
         if self._h:

@@ -420,9 +420,22 @@ void orc_dynamics(const Os2rModel* md, double dt, const double* mass_scale, cons
 
 /* ------------------------------------------------------------------------- *
  * One physics iteration (the work of one `gazebo.run()`, gazebo_runtime.py:76).
+ *
+ * Two contact models:
+ *   ORC_CONTACT_CENTROID    THE SPECIFICATION (what the HIP kernels implement):
+ *                           per body one point contact at the weighted centroid of the candidates
+ *                           inside the 1 mm band, gap-based normal target, two-phase fixed-box PGS.
+ *   ORC_CONTACT_PER_VERTEX  oracle-only comparison model after the scheme SURVEY.md Appendix B
+ *                           attributes to the reference's backend [recollection of upstream
+ *                           behaviour, not checkable here]: one contact per penetrating candidate
+ *                           (z < 0), error-reduction target only (no open-gap term), friction
+ *                           pyramid coupled to the current normal impulse, cfg->pgs_iters sweeps.
+ *                           Used by tests/test_oracle_contact.py to measure how far the
+ *                           specification sits from that scheme; never on a product path.
  * ------------------------------------------------------------------------- */
-typedef struct { double J[OS2R_MAX_DOF], T[OS2R_MAX_DOF], d, target, lambda; int kind, normal_row; double bound; } Row;
+typedef struct { double J[OS2R_MAX_DOF], T[OS2R_MAX_DOF], d, target, lambda; int kind, normal_row, body; double bound, point[3]; } Row;
 /* kind: 0 normal (lambda>=0), 1 tangential (|lambda|<=mu*lambda_normal), 2 joint friction (|lambda|<=bound) */
+#define ORC_MAX_ROWS (3 * OS2R_MAX_CAND + OS2R_MAX_DOF)
 
 void orc_contact_points(const Os2rModel* md, double margin, const double (*rw)[9], const double (*ow)[3],
                         int* active, double (*pw)[3], double* gap) {
@@ -449,56 +462,77 @@ void orc_contact_points(const Os2rModel* md, double margin, const double (*rw)[9
   }
 }
 
-static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
+/* three rows (normal z, tangents x, y) of a point contact at world point pw on body b */
+static int add_contact_rows(const Os2rModel* md, const double (*rw)[9], const double (*ow)[3], int b,
+                            const double pw[3], double target_n, double mu, Row* rows, int nr) {
+  const int n = md->nq;
+  double Jp[3][OS2R_MAX_DOF];
+  for (int j = 0; j < n; ++j) {
+    if (j <= b) {
+      double aw[3] = {rw[j][md->axis[j]], rw[j][3 + md->axis[j]], rw[j][6 + md->axis[j]]};
+      double dlt[3] = {pw[0] - ow[j][0], pw[1] - ow[j][1], pw[2] - ow[j][2]}, cr[3];
+      cross3(aw, dlt, cr);
+      Jp[0][j] = cr[0]; Jp[1][j] = cr[1]; Jp[2][j] = cr[2];
+    } else { Jp[0][j] = Jp[1][j] = Jp[2][j] = 0.0; }
+  }
+  const int dirs[3] = {2, 0, 1};  /* normal z, then tangents x, y */
+  const int nrow = nr;
+  for (int t = 0; t < 3; ++t) {
+    Row* r = &rows[nr++];
+    memset(r, 0, sizeof(Row));
+    for (int j = 0; j < n; ++j) r->J[j] = Jp[dirs[t]][j];
+    r->kind = t == 0 ? 0 : 1; r->normal_row = nrow; r->bound = mu; r->body = b;
+    r->target = t == 0 ? target_n : 0.0;
+    memcpy(r->point, pw, 3 * sizeof(double));
+  }
+  return nr;
+}
+
+/* Unconstrained velocity v* = qd + dt*qdd, the inverse of the damping-augmented mass matrix and
+ * the constraint rows of the boxed LCP of this physics iteration.  Returns the number of rows. */
+static int build_problem(const Os2rConfig* cfg, int contact_model, const EnvParams* ep, const double* q, const double* qd,
+                         const double tau2[2], double* v, double* minv, Row* rows) {
   const Os2rModel* md = &cfg->model;
   const int n = md->nq;
   const double dt = cfg->dt;
-  double tau[OS2R_MAX_DOF] = {0}, qdd[OS2R_MAX_DOF], minv[OS2R_MAX_DOF * OS2R_MAX_DOF];
+  double tau[OS2R_MAX_DOF] = {0}, qdd[OS2R_MAX_DOF];
   double rw[OS2R_MAX_DOF][9], ow[OS2R_MAX_DOF][3];
   tau[md->act_dof[0]] = tau2[0];
   tau[md->act_dof[1]] = tau2[1];
   dynamics(md, ep, dt, q, qd, tau, qdd, minv, rw, ow);
-
-  double v[OS2R_MAX_DOF];
   for (int i = 0; i < n; ++i) v[i] = qd[i] + dt * qdd[i];
 
-  Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   int nr = 0;
-  if (cfg->contact) {
+  if (cfg->contact && contact_model == ORC_CONTACT_CENTROID) {
     int active[OS2R_MAX_DOF]; double pw[OS2R_MAX_DOF][3], gap[OS2R_MAX_DOF];
     orc_contact_points(md, cfg->contact_margin, rw, ow, active, pw, gap);
     for (int b = 0; b < n; ++b) {
       if (!active[b]) continue;
-      double Jp[3][OS2R_MAX_DOF];
-      for (int j = 0; j < n; ++j) {
-        if (j <= b) {
-          double aw[3] = {rw[j][md->axis[j]], rw[j][3 + md->axis[j]], rw[j][6 + md->axis[j]]};
-          double dlt[3] = {pw[b][0] - ow[j][0], pw[b][1] - ow[j][1], pw[b][2] - ow[j][2]}, cr[3];
-          cross3(aw, dlt, cr);
-          Jp[0][j] = cr[0]; Jp[1][j] = cr[1]; Jp[2][j] = cr[2];
-        } else { Jp[0][j] = Jp[1][j] = Jp[2][j] = 0.0; }
-      }
       /* gap-based non-penetration (Stewart-Trinkle): an open gap may close within the step,
        * a penetration is pushed out at the capped error-reduction velocity */
       double erv;
       if (gap[b] >= 0.0) erv = -gap[b] / dt;
       else { erv = cfg->erp * (-gap[b]) / dt; if (erv > cfg->max_erv) erv = cfg->max_erv; }
-      const int dirs[3] = {2, 0, 1};  /* normal z, then tangents x, y */
-      int nrow = nr;
-      for (int t = 0; t < 3; ++t) {
-        Row* r = &rows[nr++];
-        memset(r, 0, sizeof(Row));
-        for (int j = 0; j < n; ++j) r->J[j] = Jp[dirs[t]][j];
-        r->kind = t == 0 ? 0 : 1; r->normal_row = nrow; r->bound = ep->mu[b];
-        r->target = t == 0 ? erv : 0.0;
-      }
+      nr = add_contact_rows(md, rw, ow, b, pw[b], erv, ep->mu[b], rows, nr);
+    }
+  } else if (cfg->contact) {
+    /* comparison model: every candidate below the plane is a contact of its own */
+    for (int k = 0; k < md->ncand; ++k) {
+      const int b = md->cand_body[k];
+      const double* p = md->cand_p[k];
+      double t[3], pw[3];
+      m3_vec(rw[b], p, t);
+      for (int i = 0; i < 3; ++i) pw[i] = t[i] + ow[b][i];
+      if (!(pw[2] < 0.0)) continue;
+      double erv = cfg->erp * (-pw[2]) / dt; if (erv > cfg->max_erv) erv = cfg->max_erv;
+      nr = add_contact_rows(md, rw, ow, b, pw, erv, ep->mu[b], rows, nr);
     }
   }
   for (int j = 0; j < n; ++j) {
     if (!(ep->friction[j] > 0.0)) continue;
     Row* r = &rows[nr++];
     memset(r, 0, sizeof(Row));
-    r->J[j] = 1.0; r->kind = 2; r->bound = ep->friction[j] * dt; r->target = 0.0;
+    r->J[j] = 1.0; r->kind = 2; r->bound = ep->friction[j] * dt; r->target = 0.0; r->body = j; r->normal_row = -1;
   }
   for (int r = 0; r < nr; ++r) {
     Row* R = &rows[r];
@@ -506,18 +540,29 @@ static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, doubl
     double s = 0; for (int j = 0; j < n; ++j) s += R->J[j] * R->T[j];
     R->d = s;
   }
-  /* Projected Gauss-Seidel on the velocities, fixed sweep counts, cold start.
-   * Phase 1 (pgs_normal_iters sweeps): normal rows and joint-friction rows only; its normal
-   * impulses fix the tangential box bounds +-mu*lambda_n.  Phase 2 (pgs_iters sweeps): all rows
-   * with those fixed bounds -- a boxed LCP with a symmetric PSD matrix, i.e. a convex QP with a
-   * unique velocity solution.  (With pgs_normal_iters == 0 the bounds follow the current normal
-   * impulse inside the sweep, the classical coupled pyramid, which is ill-posed for a slender
-   * leg sliding at mu ~ 1: Painleve's paradox.) */
+  return nr;
+}
+
+/* Projected Gauss-Seidel on the velocities, fixed sweep counts, cold start.
+ * Phase 1 (normal_iters sweeps): normal rows and joint-friction rows only; its normal
+ * impulses fix the tangential box bounds +-mu*lambda_n.  Phase 2 (iters sweeps): all rows
+ * with those fixed bounds -- a boxed LCP with a symmetric PSD matrix, i.e. a convex QP with a
+ * unique velocity solution.  (With normal_iters == 0 the bounds follow the current normal
+ * impulse inside the sweep, the classical coupled pyramid, which is ill-posed for a slender
+ * leg sliding at mu ~ 1: Painleve's paradox.)  After the solve rows[r].bound of a tangential
+ * row holds the box actually used (fixed-box form) or mu (coupled form). */
+/* Stopping rule of phase 2: every 4th sweep (not the last) measures the energy it moved, the sum over the
+ * rows of |residual * impulse change| (the decrease of the QP objective up to a factor <= 2); the
+ * environment stops sweeping when that is <= tol.  tol == 0 stops at exact fixed points only, which
+ * changes nothing (every further sweep would reproduce the state bit for bit). */
+#define ORC_PGS_GROUP 4
+static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, double* v) {
   for (int phase = 0; phase < 2; ++phase) {
-    const int sweeps = phase == 0 ? cfg->pgs_normal_iters : cfg->pgs_iters;
-    if (phase == 1 && cfg->pgs_normal_iters > 0)
+    const int sweeps = phase == 0 ? normal_iters : iters;
+    if (phase == 1 && normal_iters > 0)
       for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
     for (int it = 0; it < sweeps; ++it) {
+      double moved = 0.0;
       for (int r = 0; r < nr; ++r) {
         Row* R = &rows[r];
         if (!(R->d > 0.0)) continue;
@@ -525,29 +570,99 @@ static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, doubl
         double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
         double lam = R->lambda - res / R->d, lo, hi;
         if (R->kind == 0) { lo = 0.0; hi = INFINITY; }
-        else if (R->kind == 1) { hi = cfg->pgs_normal_iters > 0 ? R->bound : R->bound * rows[R->normal_row].lambda; lo = -hi; }
+        else if (R->kind == 1) { hi = normal_iters > 0 ? R->bound : R->bound * rows[R->normal_row].lambda; lo = -hi; }
         else { hi = R->bound; lo = -hi; }
         if (lam < lo) lam = lo;
         if (lam > hi) lam = hi;
         double dl = lam - R->lambda;
         R->lambda = lam;
+        moved += fabs(res) * fabs(dl);
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
+      if (phase == 1 && (it + 1) % ORC_PGS_GROUP == 0 && it + 1 < sweeps && moved <= tol) break;
     }
   }
-  for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += dt * v[i]; }
+}
+
+static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
+  const int n = cfg->model.nq;
+  double v[OS2R_MAX_DOF], minv[OS2R_MAX_DOF * OS2R_MAX_DOF];
+  if (contact_model == ORC_CONTACT_CENTROID) {
+    Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+    const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
+    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, v);
+  } else {
+    Row* rows = (Row*)malloc(sizeof(Row) * ORC_MAX_ROWS);
+    const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
+    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, v);
+    free(rows);
+  }
+  for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += cfg->dt * v[i]; }
+}
+
+static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
+  substep_model(cfg, ORC_CONTACT_CENTROID, ep, q, qd, tau2);
+}
+
+static void params_from(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
+                        const double* mu, double gravity_z, EnvParams* ep) {
+  nominal_params(&cfg->model, ep);
+  int n = cfg->model.nq;
+  if (mass_scale) memcpy(ep->mass_scale, mass_scale, n * sizeof(double));
+  if (damping) memcpy(ep->damping, damping, n * sizeof(double));
+  if (friction) memcpy(ep->friction, friction, n * sizeof(double));
+  if (mu) memcpy(ep->mu, mu, n * sizeof(double));
+  ep->gravity_z = gravity_z;
 }
 
 void orc_substep(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
                  const double* mu, double gravity_z, double* q, double* qd, const double tau2[2]) {
-  EnvParams ep; nominal_params(&cfg->model, &ep);
-  int n = cfg->model.nq;
-  if (mass_scale) memcpy(ep.mass_scale, mass_scale, n * sizeof(double));
-  if (damping) memcpy(ep.damping, damping, n * sizeof(double));
-  if (friction) memcpy(ep.friction, friction, n * sizeof(double));
-  if (mu) memcpy(ep.mu, mu, n * sizeof(double));
-  ep.gravity_z = gravity_z;
+  EnvParams ep; params_from(cfg, mass_scale, damping, friction, mu, gravity_z, &ep);
   substep(cfg, &ep, q, qd, tau2);
+}
+
+void orc_substep_model(const Os2rConfig* cfg, int contact_model, const double* mass_scale, const double* damping,
+                       const double* friction, const double* mu, double gravity_z, double* q, double* qd,
+                       const double tau2[2]) {
+  EnvParams ep; params_from(cfg, mass_scale, damping, friction, mu, gravity_z, &ep);
+  substep_model(cfg, contact_model, &ep, q, qd, tau2);
+}
+
+/* The boxed LCP of one physics iteration, laid open for independent checks (tests/test_oracle_contact.py):
+ * builds the rows for the state (q, qd), solves them with the configuration's sweep counts and returns
+ * the problem AND the solution.  Arrays are sized for max_rows rows; returns the number of rows (or -1
+ * if max_rows is too small).  vstar: unconstrained velocity; v_out: velocity after the solve; bound: mu
+ * (tangential) or friction*dt (joint) as built; box: the half-width actually used for the row in the
+ * last sweep; lambda: impulses after the solve; point: world contact point of the row. */
+int orc_contact_problem(const Os2rConfig* cfg, int contact_model, const double* mass_scale, const double* damping,
+                        const double* friction, const double* mu, double gravity_z, const double* q,
+                        const double* qd, const double tau2[2], int max_rows, double* vstar, double* minv,
+                        double* J, double* target, int32_t* kind, int32_t* normal_row, int32_t* body,
+                        double* bound, double* box, double* lambda, double* point, double* v_out) {
+  EnvParams ep; params_from(cfg, mass_scale, damping, friction, mu, gravity_z, &ep);
+  const int n = cfg->model.nq;
+  Row* rows = (Row*)malloc(sizeof(Row) * ORC_MAX_ROWS);
+  double v[OS2R_MAX_DOF];
+  const int nr = build_problem(cfg, contact_model, &ep, q, qd, tau2, v, minv, rows);
+  if (nr > max_rows) { free(rows); return -1; }
+  for (int i = 0; i < n; ++i) vstar[i] = v[i];
+  for (int r = 0; r < nr; ++r) {
+    for (int j = 0; j < n; ++j) J[r * n + j] = rows[r].J[j];
+    target[r] = rows[r].target; kind[r] = rows[r].kind; normal_row[r] = rows[r].normal_row; body[r] = rows[r].body;
+    bound[r] = rows[r].bound;
+    for (int i = 0; i < 3; ++i) point[3 * r + i] = rows[r].point[i];
+  }
+  const int coupled = contact_model != ORC_CONTACT_CENTROID || cfg->pgs_normal_iters == 0;
+  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, v);
+  for (int r = 0; r < nr; ++r) {
+    lambda[r] = rows[r].lambda;
+    if (rows[r].kind == 0) box[r] = INFINITY;
+    else if (rows[r].kind == 1) box[r] = coupled ? rows[r].bound * rows[rows[r].normal_row].lambda : rows[r].bound;
+    else box[r] = rows[r].bound;
+  }
+  for (int i = 0; i < n; ++i) v_out[i] = v[i];
+  free(rows);
+  return nr;
 }
 
 /* ------------------------------------------------------------------------- *
@@ -563,6 +678,7 @@ struct OrcSim {
   int32_t* steps; uint32_t* episode; uint8_t* pose;
   uint64_t step_count;
   int nthreads;
+  int contact_model;   /* ORC_CONTACT_*: the specification unless a test asks for the comparison model */
 };
 
 static void load_params(const OrcSim* s, int64_t e, EnvParams* ep) {
@@ -662,6 +778,7 @@ void orc_destroy(OrcSim* s) {
 }
 
 void orc_set_threads(OrcSim* s, int n) { s->nthreads = n < 1 ? 1 : n; }
+void orc_set_contact_model(OrcSim* s, int model) { s->contact_model = model; }
 
 static void observe_env(const OrcSim* s, int64_t e, double* obs) {
   const int n = s->cfg.model.nq; const int64_t N = s->N;
@@ -699,7 +816,7 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
     double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
     EnvParams ep; load_params(s, e, &ep);
     for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
-    for (int k = 0; k < cfg->substeps; ++k) substep(cfg, &ep, q, qd, tau);      /* gazebo_runtime.py:70-77 */
+    for (int k = 0; k < cfg->substeps; ++k) substep_model(cfg, s->contact_model, &ep, q, qd, tau);      /* gazebo_runtime.py:70-77 */
     int bad = 0;
     for (int i = 0; i < n; ++i) { if (!isfinite(q[i]) || !isfinite(qd[i])) bad = 1; s->q[i * N + e] = q[i]; s->qd[i * N + e] = qd[i]; }
     /* action_history.appendleft (monopod.py:232-235) */

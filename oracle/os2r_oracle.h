@@ -32,10 +32,22 @@ void orc_contact_points(const Os2rModel* md, double margin, const double (*rw)[9
 void orc_substep(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
                  const double* mu, double gravity_z, double* q, double* qd, const double tau2[2]);
 
+/* contact models of the oracle: the specification, and an oracle-only comparison model (os2r_oracle.c) */
+enum { ORC_CONTACT_CENTROID = 0, ORC_CONTACT_PER_VERTEX = 1 };
+void orc_substep_model(const Os2rConfig* cfg, int contact_model, const double* mass_scale, const double* damping,
+                       const double* friction, const double* mu, double gravity_z, double* q, double* qd,
+                       const double tau2[2]);
+int orc_contact_problem(const Os2rConfig* cfg, int contact_model, const double* mass_scale, const double* damping,
+                        const double* friction, const double* mu, double gravity_z, const double* q,
+                        const double* qd, const double tau2[2], int max_rows, double* vstar, double* minv,
+                        double* J, double* target, int32_t* kind, int32_t* normal_row, int32_t* body,
+                        double* bound, double* box, double* lambda, double* point, double* v_out);
+
 /* batched simulator mirroring include/os2r.h on host arrays */
 int orc_create(const Os2rConfig* cfg, OrcSim** out);
 void orc_destroy(OrcSim* s);
 void orc_set_threads(OrcSim* s, int n);
+void orc_set_contact_model(OrcSim* s, int model);
 int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);
 int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint8_t* done, double* term_obs);
 int orc_get_state(OrcSim* s, double* q, double* qd);

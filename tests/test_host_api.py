@@ -198,7 +198,7 @@ def test_capi_library_exports_every_declared_symbol():
     assert lib.os2r_abi_version() == abi.ABI_VERSION
     lib.os2r_last_error.restype = ctypes.c_char_p
     # struct layout agreement between the header (as compiled) and the ctypes mirror
-    assert ctypes.sizeof(abi.Os2rConfig) == ctypes.sizeof(abi.Os2rModel) + ctypes.sizeof(abi.Os2rTaskSpec) + 88
+    assert ctypes.sizeof(abi.Os2rConfig) == ctypes.sizeof(abi.Os2rModel) + ctypes.sizeof(abi.Os2rTaskSpec) + 96
     # a null config is rejected with an error code and a message, without touching a device
     out = ctypes.c_void_p()
     assert _lib.load().os2r_create(None, ctypes.byref(out)) == abi.ERR_INVALID
