@@ -1,0 +1,105 @@
+"""Independent numpy checks of the contact half of the oracle (tests/test_oracle_contact.py).
+
+Nothing here shares code with oracle/os2r_oracle.c: the boxed LCP of one physics iteration is taken as data
+(oracle_py.contact_problem) and
+  * restated: the two-phase projected Gauss-Seidel of DESIGN.md 3.2 step 6, with its stopping rule;
+  * solved exactly: enumeration of the active sets of the fixed-box problem (a convex QP: the first
+    assignment that meets the optimality conditions IS the solution; A is only positive semi-definite, so the
+    free block is solved in the least-squares sense and the velocity, which is unique, is compared);
+  * certified: the optimality (KKT) residual of any candidate solution, in whitened units.
+"""
+import itertools
+
+import numpy as np
+
+
+def lcp_matrices(p):
+    """A = J Minv J^T, c = J v* - target, and the fixed box [lo, hi] of phase 2."""
+    J, minv = p["J"], p["minv"]
+    A = J @ minv @ J.T
+    c = J @ p["vstar"] - p["target"]
+    lo = np.where(p["kind"] == 0, 0.0, -p["box"])
+    hi = np.where(p["kind"] == 0, np.inf, p["box"])
+    return A, c, lo, hi
+
+
+def velocity(p, lam):
+    return p["vstar"] + p["minv"] @ (p["J"].T @ lam)
+
+
+def kkt_residual(A, c, lo, hi, lam):
+    """max over rows of the violation of (lam = lo: w >= 0 | lam = hi: w <= 0 | else w = 0), w = A lam + c,
+    each row scaled by sqrt(A_rr) (the row's norm in the whitened metric); rows with lo == hi carry no condition."""
+    w = A @ lam + c
+    scale = np.sqrt(np.maximum(np.diag(A), 1e-300))
+    span = np.maximum(np.abs(lam), 1e-300)
+    at_lo = lam <= lo + 1e-12 * span
+    at_hi = lam >= hi - 1e-12 * span
+    v = np.where(at_lo & at_hi, 0.0, np.where(at_lo, np.maximum(-w, 0), np.where(at_hi, np.maximum(w, 0), np.abs(w))))
+    return float((v / scale).max())
+
+
+def enumerate_exact(A, c, lo, hi, tol=1e-9):
+    """-> (lam, residual) of the first active-set assignment that satisfies the optimality conditions."""
+    nr = len(c)
+    opts = []
+    for r in range(nr):
+        if hi[r] - lo[r] <= 0: opts.append("P")            # pinned: both bounds coincide
+        elif np.isinf(hi[r]): opts.append("FL")
+        else: opts.append("FLU")
+    scale = np.sqrt(np.maximum(np.diag(A), 1e-300))
+    best = None
+    for st in itertools.product(*opts):
+        st = np.array(st)
+        F = st == "F"
+        lam = np.where(st == "U", hi, lo).astype(float)
+        lam[F] = 0.0
+        if F.any():
+            rhs = -(c[F] + A[np.ix_(F, ~F)] @ lam[~F])
+            lam[F] = np.linalg.lstsq(A[np.ix_(F, F)], rhs, rcond=1e-13)[0]
+        w = A @ lam + c
+        v = np.where(st == "P", 0.0, np.where(st == "L", np.maximum(-w, 0) / scale, np.where(st == "U", np.maximum(w, 0) / scale,
+                     np.maximum(np.abs(w) / scale, np.maximum(np.maximum(lo - lam, lam - np.where(np.isinf(hi), lam, hi)), 0) * scale))))
+        res = float(v.max())
+        if best is None or res < best[1]:
+            best = (lam.copy(), res)
+        if res < tol:
+            break
+    return best
+
+
+def pgs_two_phase(p, normal_iters=3, iters=20, tol=1e-24, group=4):
+    """The specification's solver on the exported rows: -> (v, lam, box, sweeps of phase 2 actually run)."""
+    J, minv, t, kind, nrow = p["J"], p["minv"], p["target"], p["kind"], p["normal_row"]
+    nr = len(t)
+    T = J @ minv                      # T[r] = Minv J_r (Minv symmetric)
+    d = np.einsum("rj,rj->r", J, T)
+    v = p["vstar"].copy()
+    lam = np.zeros(nr)
+    box = p["bound"].copy()
+    ran = 0
+    for phase in (0, 1):
+        if phase == 1:
+            for r in range(nr):
+                if kind[r] == 1:
+                    box[r] = p["bound"][r] * lam[nrow[r]]
+        for it in range(normal_iters if phase == 0 else iters):
+            moved = 0.0
+            for r in range(nr):
+                if not d[r] > 0 or (phase == 0 and kind[r] == 1):
+                    continue
+                res = J[r] @ v - t[r]
+                new = lam[r] - res / d[r]
+                if kind[r] == 0:
+                    new = max(new, 0.0)
+                else:
+                    new = min(max(new, -box[r]), box[r])
+                dl = new - lam[r]
+                lam[r] = new
+                moved += abs(res) * abs(dl)
+                v += T[r] * dl
+            if phase == 1:
+                ran += 1
+                if (it + 1) % group == 0 and it + 1 < iters and moved <= tol:
+                    break
+    return v, lam, box, ran
