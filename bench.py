@@ -180,7 +180,11 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pgs-iters", type=int, default=20)
     ap.add_argument("--pgs-normal-iters", type=int, default=3)
-    ap.add_argument("--pgs-tol", type=float, default=1e-24, help="stopping tolerance of the solver's sweeps [J] (0: fixed counts)")
+    ap.add_argument("--pgs-tol", type=float, default=None,
+                    help="stopping tolerance of the solver's sweeps [J] (default: 1e-24 for f64, 1e-13 for f32; 0: fixed counts)")
+    ap.add_argument("--dump-gathered", default=None,
+                    help="with --gather-obs: rank 0 saves the observations / rewards / done flags gathered in the last "
+                         "timed step to this .npz (tests compare them with a single handle of all the environments)")
     ap.add_argument("--no-count", action="store_true", help="skip the counting replay of the timed window")
     ap.add_argument("--cpu-envs", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -253,12 +257,15 @@ def main():
             ev0.record()
             obs, rew, done, _ = sim.step(None, want_terminal=False)
             ev1.record()
-            for t in (obs, rew, done):
-                gather_to_rank0(t.cpu() if host else t, args.envs_per_gpu * world)
+            gathered = [gather_to_rank0(t.cpu() if host else t, args.envs_per_gpu * world) for t in (obs, rew, done)]
             ev1.synchronize()
             kernel_ms += ev0.elapsed_time(ev1)
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.gather_obs and args.dump_gathered and rank == 0:
+        import numpy as np
+        np.savez(args.dump_gathered, obs=gathered[0].cpu().numpy(), reward=gathered[1].cpu().numpy(), done=gathered[2].cpu().numpy(),
+                 steps_run=args.preroll + args.warmup + args.steps)
     if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

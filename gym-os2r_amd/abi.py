@@ -7,7 +7,7 @@ task drives both sides of a parity check.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Mapping
+from typing import Mapping, Optional
 
 ABI_VERSION = 2
 MAX_DOF = 5
@@ -90,6 +90,7 @@ class Os2rTaskSpec(C.Structure):
         ("dr_damping_lo", C.c_double), ("dr_damping_hi", C.c_double),
         ("dr_mu_base", C.c_double), ("dr_mu_lo", C.c_double), ("dr_mu_hi", C.c_double),
         ("dr_gravity_mean", C.c_double), ("dr_gravity_std", C.c_double),
+        ("gravity_rollouts", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -202,6 +203,7 @@ def task_struct(t: Mapping) -> Os2rTaskSpec:
                  "dr_damping_hi", "dr_mu_base", "dr_mu_lo", "dr_mu_hi", "dr_gravity_mean",
                  "dr_gravity_std"):
         setattr(s, name, float(t[name]))
+    s.gravity_rollouts = int(t.get("gravity_rollouts", 0))
     return s
 
 
@@ -209,7 +211,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
                   dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 3,
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
-                  contact_margin: float = 1e-3, pgs_tol: float = 1e-24) -> Os2rConfig:
+                  contact_margin: float = 1e-3, pgs_tol: Optional[float] = None) -> Os2rConfig:
     c = Os2rConfig()
     c.abi_version = ABI_VERSION
     c.dtype = int(dtype)
@@ -226,7 +228,9 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     c.erp = float(erp)
     c.max_erv = float(max_erv)
     c.contact_margin = float(contact_margin)
-    c.pgs_tol = float(pgs_tol)
+    # stopping tolerance of the sweeps [J]: far below the solver's truncation error, above the rounding floor of the
+    # measure in the handle's arithmetic (fp64: 1e-24; fp32: 1e-13)
+    c.pgs_tol = float(pgs_tol) if pgs_tol is not None else (1e-24 if dtype == F64 else 1e-13)
     c.model = model_struct(model)
     c.task = task_struct(task)
     return c

@@ -19,6 +19,7 @@ class HipVecEnv:
         self.waiting = False
         self.closed = False
         self._actions = None
+        self._per_env = {}
 
     def step_async(self, actions):
         self._actions = actions
@@ -37,7 +38,11 @@ class HipVecEnv:
         return self.env.reset()
 
     def seed(self, seed=None):
-        return self.env.seed(seed)
+        """SubprocVecEnv seeds worker r with seed + r (subproc_vec_env.py:160-164); here every random stream is keyed
+        by (seed, global env index), so one seed gives every environment its own stream: -> [seed] * num_envs."""
+        out = self.env.seed(seed)
+        s0 = out[0] if isinstance(out, (list, tuple)) and out else out
+        return [s0 for _ in range(self.num_envs)]
 
     def close(self):
         if not self.closed:
@@ -51,16 +56,36 @@ class HipVecEnv:
             return self.env.get_state_info(state, actions)
         return [self.env.get_state_info(s, a) for s, a in zip(state, actions)]
 
+    # One batched runtime stands for all the environments: an attribute of it (task, spaces, reward class ...)
+    # is shared by construction, where SubprocVecEnv keeps one copy per worker process
+    # (common/vec_env/subproc_vec_env.py:125-214).  `indices` therefore selects how many answers come back;
+    # a per-environment value -- a sequence with one entry per environment of the batch, e.g. what
+    # `set_attr` stored for a subset -- is indexed by it.
     def get_attr(self, attr_name, indices=None):
-        n = len(self._indices(indices))
-        return [getattr(self.env, attr_name)] * n
+        idx = self._indices(indices)
+        per_env = self._per_env.get(attr_name)
+        shared = getattr(self.env, attr_name) if hasattr(self.env, attr_name) else getattr(self.env.unwrapped, attr_name)
+        if per_env is None:
+            return [shared for _ in idx]
+        return [per_env.get(i, shared) for i in idx]
 
     def set_attr(self, attr_name, value, indices=None):
-        setattr(self.env.unwrapped, attr_name, value)
+        """All environments (indices None): the attribute of the shared runtime is set.  A subset: the value is
+        recorded for those environments only and returned by `get_attr` for them; attributes that the kernel
+        reads per environment have their own per-environment interface (`HipSim.set_params`, `set_state`)."""
+        if indices is None:
+            setattr(self.env.unwrapped, attr_name, value)
+            self._per_env.pop(attr_name, None)
+            return
+        slot = self._per_env.setdefault(attr_name, {})
+        for i in self._indices(indices):
+            slot[i] = value
 
     def env_method(self, method_name, *args, indices=None, **kwargs):
-        n = len(self._indices(indices))
-        return [getattr(self.env, method_name)(*args, **kwargs)] * n
+        idx = self._indices(indices)
+        fn = getattr(self.env, method_name)
+        result = fn(*args, **kwargs)                  # one call serves the batch
+        return [result for _ in idx]
 
     def get_images(self):
         raise NotImplementedError("headless stepper: no rendering")
@@ -71,9 +96,12 @@ class HipVecEnv:
     def _indices(self, indices):
         if indices is None:
             return list(range(self.num_envs))
-        if isinstance(indices, int):
-            return [indices]
-        return list(indices)
+        if isinstance(indices, (int, np.integer)):
+            indices = [int(indices)]
+        idx = [int(i) for i in indices]
+        if any(i < 0 or i >= self.num_envs for i in idx):
+            raise IndexError(f"env index out of range for {self.num_envs} environments")
+        return idx
 
     @property
     def unwrapped(self):

@@ -182,6 +182,8 @@ void fill_task(const Os2rConfig& cfg, DevTask<T>& d) {
   for (int i = 0; i < 6; ++i) d.leg_def[i] = t.leg_def[i];
   d.dof_yaw = t.dof_yaw; d.dof_pitch = t.dof_pitch; d.dof_bc = t.dof_bc; d.dof_hip = t.dof_hip; d.dof_knee = t.dof_knee;
   d.randomize_params = t.randomize_params;
+  d.gravity_rollouts = t.gravity_rollouts;
+  d.dr_gravity_mean = t.dr_gravity_mean; d.dr_gravity_std = t.dr_gravity_std;
   d.dr_mass_lo = t.dr_mass_lo; d.dr_mass_hi = t.dr_mass_hi;
   d.dr_friction_lo = t.dr_friction_lo; d.dr_friction_hi = t.dr_friction_hi;
   d.dr_damping_lo = t.dr_damping_lo; d.dr_damping_hi = t.dr_damping_hi;
@@ -225,6 +227,7 @@ int validate(const Os2rConfig* c, std::string& why) {
   if (!(c->dt > 0.0)) { why = "dt must be positive"; return 1; }
   if (c->pgs_iters < 0 || c->pgs_iters > 10000) { why = "pgs_iters out of range"; return 1; }
   if (!(c->contact_margin >= 0.0)) { why = "contact_margin must be >= 0"; return 1; }
+  if (t.gravity_rollouts < 0) { why = "gravity_rollouts must be >= 0"; return 1; }
   if (c->pgs_normal_iters < 0 || c->pgs_normal_iters > 10000) { why = "pgs_normal_iters out of range"; return 1; }
   if (!(c->pgs_tol >= 0.0)) { why = "pgs_tol must be >= 0"; return 1; }
   return 0;

@@ -100,6 +100,8 @@ struct DevTask {
   double leg_def[6];
   int dof_yaw, dof_pitch, dof_bc, dof_hip, dof_knee;
   int randomize_params;
+  int gravity_rollouts;
+  double dr_gravity_mean, dr_gravity_std;
   double dr_mass_lo, dr_mass_hi, dr_friction_lo, dr_friction_hi, dr_damping_lo, dr_damping_hi;
   double dr_mu_base, dr_mu_lo, dr_mu_hi;
   double nominal_damping[OS2R_MAX_DOF];
@@ -303,10 +305,30 @@ __device__ __forceinline__ float sqrt_t(float x) { return sqrtf(x); }
 // library routine as the wave-uniform fallback beyond 2^19*pi/2; the kernels are the classical
 // minimax polynomials on [-pi/4, pi/4] (fdlibm k_sin / k_cos coefficients), ~1 ulp.
 __device__ __forceinline__ bool sincos_in_range(double x) { return fabs(x) < 8.2e5; }
-__device__ __forceinline__ bool sincos_in_range(float) { return false; }   // f32: library routine
+__device__ __forceinline__ bool sincos_in_range(float x) { return fabsf(x) < 200.0f; }   // beyond: library routine
 __device__ __forceinline__ void sincos_lib(double x, double& s, double& c) { sincos(x, &s, &c); }
 __device__ __forceinline__ void sincos_lib(float x, float& s, float& c) { sincosf(x, &s, &c); }
-__device__ __forceinline__ void sincos_fast(float x, float& s, float& c) { sincosf(x, &s, &c); }
+// fp32: three-term Cody-Waite reduction (exact products for |k| < 2^9, i.e. |x| < 200 rad with margin) and the
+// minimax kernels of sinf / cosf on [-pi/4, pi/4] (Cephes coefficients), ~1 ulp
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c) {
+  const float k = __builtin_rintf(x * 0.636619772f);
+  float r = __builtin_fmaf(-k, 1.5703125f, x);                   // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188e-8
+  r = __builtin_fmaf(-k, 4.837512969970703125e-4f, r);
+  r = __builtin_fmaf(-k, 7.54978995489188e-8f, r);
+  const float z = r * r;
+  float ps = -1.9515295891e-4f;
+  ps = __builtin_fmaf(ps, z, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  const float sr = __builtin_fmaf(r * z, ps, r);
+  float pc = 2.443315711809948e-5f;
+  pc = __builtin_fmaf(pc, z, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  const float cr = __builtin_fmaf(z * z, pc, __builtin_fmaf(-0.5f, z, 1.0f));
+  const int n = (int)k;
+  const float a = (n & 1) ? cr : sr, b = (n & 1) ? sr : cr;
+  s = (n & 2) ? -a : a;
+  c = ((n + 1) & 2) ? -b : b;
+}
 __device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
   const double k = __builtin_rint(x * 0x1.45f306dc9c883p-1);          // x * 2/pi
   double r = __builtin_fma(-k, 0x1.921fb54442d18p+0, x);               // pi/2 = C1 + C2 + ...
@@ -341,7 +363,10 @@ __device__ __forceinline__ double rcp_t(double x) {
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   return r;
 }
-__device__ __forceinline__ float rcp_t(float x) { return 1.0f / x; }
+__device__ __forceinline__ float rcp_t(float x) {
+  float r = __builtin_amdgcn_rcpf(x);              // 1 ulp estimate; one Newton step
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
 __device__ __forceinline__ double rsqrt_t(double x) {
   double r = __builtin_amdgcn_rsq(x);
   // r <- r * (1.5 - 0.5 x r^2), twice
@@ -349,7 +374,10 @@ __device__ __forceinline__ double rsqrt_t(double x) {
   r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
   return r;
 }
-__device__ __forceinline__ float rsqrt_t(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ float rsqrt_t(float x) {
+  float r = __builtin_amdgcn_rsqf(x);
+  return r * __builtin_fmaf(-0.5f * x * r, r, 1.5f);
+}
 
 __device__ __forceinline__ double fmax_t(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float fmax_t(float a, float b) { return fmaxf(a, b); }
@@ -450,7 +478,7 @@ struct Params<T, MD, true> {
 // Diagnostic phase stamps (separate build with -DOS2R_STAMPS, never in the shipped library):
 // shader-clock ticks per phase are summed per wave and written by lane 0 to a debug buffer that
 // nothing else reads (cdna_hip_programming.md, "In-kernel stamps").
-constexpr int kStamps = 24;   // 0..11 phases, 12.. finer marks inside the dynamics
+constexpr int kStamps = 26;   // 0..11 phases, 12..23 finer marks inside the dynamics, 24/25 shader-clock and 100 MHz real-time ticks of the wave
 #ifdef OS2R_STAMPS
 #define OS2R_STAMP(idx)                                                                        \
   do {                                                                                         \
@@ -548,15 +576,15 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const T d = dt * qd[i], z = d * d;
-        T p = __builtin_fma(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
-        p = __builtin_fma(z, p, T(-1.0 / 6.0));
-        const T sd = __builtin_fma(d * z, p, d);
-        T r = __builtin_fma(z, T(-1.0 / 720.0), T(1.0 / 24.0));
-        r = __builtin_fma(z, r, T(-0.5));
+        T p = fma_t(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
+        p = fma_t(z, p, T(-1.0 / 6.0));
+        const T sd = fma_t(d * z, p, d);
+        T r = fma_t(z, T(-1.0 / 720.0), T(1.0 / 24.0));
+        r = fma_t(z, r, T(-0.5));
         const T cm = z * r;
         const T s0 = sn[i], c0 = cs[i];
-        sn[i] = s0 + __builtin_fma(c0, sd, s0 * cm);
-        cs[i] = c0 + __builtin_fma(-s0, sd, c0 * cm);
+        sn[i] = s0 + fma_t(c0, sd, s0 * cm);
+        cs[i] = c0 + fma_t(-s0, sd, c0 * cm);
       }
     } else if (ok) {
       // one range check for all joints of the lane, so the five evaluations are straight-line code
@@ -951,14 +979,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
             for (int c = 0; c < CH; ++c) {
               if (kk + c < k1) {
                 if (MD::cand_starts_run(b, kk + c, ga)) {
-                  W += Wg; S[ga] = __builtin_fma(pg, Wg, S[ga]);
+                  W += Wg; S[ga] = fma_t(pg, Wg, S[ga]);
                   Wg = T(0); pg = d[3 * c + ga];
-                  base = __builtin_fma(-Rw[6 + ga], pg, mo);
+                  base = fma_t(-Rw[6 + ga], pg, mo);
                 }
                 const T p1 = d[3 * c + a1], p2 = d[3 * c + a2];
-                const T mz = __builtin_fma(-Rw[6 + a1], p1, __builtin_fma(-Rw[6 + a2], p2, base));
+                const T mz = fma_t(-Rw[6 + a1], p1, fma_t(-Rw[6 + a2], p2, base));
                 const T wgt = fmax_t(mz, T(0));
-                Wg += wgt; S[a1] = __builtin_fma(wgt, p1, S[a1]); S[a2] = __builtin_fma(wgt, p2, S[a2]);
+                Wg += wgt; S[a1] = fma_t(wgt, p1, S[a1]); S[a2] = fma_t(wgt, p2, S[a2]);
               }
             }
           };
@@ -974,7 +1002,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
               weigh(bB, kk + CH);
             }
           }
-          W += Wg; S[ga] = __builtin_fma(pg, Wg, S[ga]);
+          W += Wg; S[ga] = fma_t(pg, Wg, S[ga]);
           sx = S[0]; sy = S[1]; sz = S[2];
         } else {
         T bufA[3 * CH], bufB[3 * CH];

@@ -48,6 +48,8 @@ static bool layout_is(const StepArgs<T>& a) {
 // fp64 only: the counting variants (os2r_set_work_counters) of the layout kernels
 [[maybe_unused]] constexpr bool kHaveCounting = sizeof(T) == 8;
 
+#define OS2R_LAUNCH(STD, ...) hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, STD, ##__VA_ARGS__>), grid, block, 0, s, a)
+
 template <typename MD, bool CONTACT, bool DR>
 static int launch_step(const StepArgs<T>& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave)), block(kWave);
@@ -60,7 +62,7 @@ static int launch_step(const StepArgs<T>& a, hipStream_t s) {
           if (a.counters) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA, true>), grid, block, 0, s, a); return 0; }
         }
         if (a.counters) return 1;
-        hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA>), grid, block, 0, s, a);
+        OS2R_LAUNCH(MD::kStatic, LayA);
         return 0;
       }
 #if OS2R_UNIT == 1
@@ -69,17 +71,17 @@ static int launch_step(const StepArgs<T>& a, hipStream_t s) {
           if (a.counters) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB, true>), grid, block, 0, s, a); return 0; }
         }
         if (a.counters) return 1;
-        hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB>), grid, block, 0, s, a);
+        OS2R_LAUNCH(MD::kStatic, LayB);
         return 0;
       }
 #endif
     }
 #endif
     if (a.counters) return 1;
-    hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic>), grid, block, 0, s, a);
+    OS2R_LAUNCH(MD::kStatic);
   } else {
     if (a.counters) return 1;
-    hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, false>), grid, block, 0, s, a);
+    OS2R_LAUNCH(false);
   }
   return 0;
 }

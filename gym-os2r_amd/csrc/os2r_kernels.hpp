@@ -245,6 +245,8 @@ template <typename T, int NQ>
 struct ParamVals {
   T ms[NQ], dm[NQ], fr[NQ], mu_[NQ];
   bool fresh = false;
+  T gravity = T(0);          // drawn anew after every `gravity_rollouts` rollouts of the environment
+  bool gravity_fresh = false;
 };
 
 template <typename T, typename MD, bool DR>
@@ -318,6 +320,14 @@ __device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uin
       }
       par.fresh = true;
     }
+    // randomize_physics of the reference runs when its simulator is re-created, every `num_physics_rollouts`
+    // rollouts (randomizers/monopod.py:36-41,56-61): `epi` rollouts of this environment are over now
+    if (ts->reset_mode == OS2R_RESET_RANDOM && ts->gravity_rollouts > 0 && epi > 0u && epi % (uint32_t)ts->gravity_rollouts == 0u) {
+      double z0, z1;
+      normal2(A.seed, genv, kStreamGravity, epi / (uint32_t)ts->gravity_rollouts, 0, z0, z1);
+      par.gravity = (T)(ts->dr_gravity_mean + ts->dr_gravity_std * z0);
+      par.gravity_fresh = true;
+    }
   }
 }
 
@@ -345,6 +355,7 @@ __device__ __forceinline__ void store_params(const StepArgs<T>& A, long long e, 
       A.mu[i * A.N + e] = pv.mu_[i];
     }
   }
+  if (pv.gravity_fresh) A.gravity[e] = pv.gravity;
 }
 
 // Coalesced [N][D] row-major store of one wave's observation tile: the 64 rows of a wave are
@@ -398,6 +409,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr bool kCandInLds = CONTACT && MD::CMASK != 0u && !MD::kStatic;
 #ifdef OS2R_STAMPS
   const unsigned long long stamp_entry = __builtin_amdgcn_s_memtime();
+  const unsigned long long real_entry = __builtin_amdgcn_s_memrealtime();
 #endif
   __shared__ T tile[lds_words<NQ>() + (kCandInLds ? kCandWords : 0)];
   const int lane = threadIdx.x;
@@ -530,13 +542,20 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   }
 #ifdef OS2R_STAMPS
   stamps[11] = __builtin_amdgcn_s_memtime() - stamp_prev;   // the state and flag stores, issued
+  // the wave's life in shader-clock ticks and in ticks of the constant 100 MHz counter: their quotient is the clock
+  // the chip held under this load (MI355X_MICROARCH.md, DVFS give-back (6))
+  stamps[24] = __builtin_amdgcn_s_memtime() - stamp_entry;
+  stamps[25] = __builtin_amdgcn_s_memrealtime() - real_entry;
   if (A.debug && lane == 0)
     for (int k = 0; k < kStamps; ++k) A.debug[blockIdx.x * kStamps + k] = stamps[k];
 #endif
 }
 
-// fp32 state fits two waves per SIMD (<= 256 registers, 17.7 KB LDS): the second wave hides what a lone
-// wave pays for in full (branches, LDS hand-overs); +28 % at 131 072 envs per GPU.  fp64 needs ~450 registers.
+// Registers decide how many waves share a SIMD.  fp64 state needs ~370 registers (256 VGPR + AGPR copies): one wave.
+// The fp32 kernels need 200 -- hardware reciprocal / rsqrt estimates with one Newton step instead of the IEEE divide
+// and sqrt expansions, a fp32 Cody-Waite sincos, no SLP vectorisation (csrc/Makefile) -- and are built for two waves
+// per SIMD without scratch: the second wave takes the issue slots a lone wave leaves empty (a lone wave issues one
+// VALU instruction every 4 cycles, the SIMD takes an fp32 one every 2), 1.6x from 131 072 envs per GPU on.
 #define OS2R_STEP_KERNEL_ATTRS(REAL) \
   __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
 

@@ -16,5 +16,10 @@ from .monopod_no_rand import _EnvWrapper
 class MonopodEnvRandomizer(_EnvWrapper):
     def __init__(self, env: Callable, num_physics_rollouts: int = 0, **kwargs):
         super().__init__(env, **kwargs)
-        self.num_physics_rollouts = num_physics_rollouts
-        self.env.configure_reset(abi.RESET_RANDOM, randomize_params=True)
+        # The reference draws gravity in randomize_physics, which runs when the simulator is (re)created: once per
+        # process with the default 0, after every `num_physics_rollouts` rollouts otherwise
+        # (randomizers/monopod.py:36-41,56-61,371).  Here: per environment, in the reset of the step kernel.
+        if int(num_physics_rollouts) < 0:
+            raise ValueError("num_physics_rollouts must be >= 0")
+        self.num_physics_rollouts = int(num_physics_rollouts)
+        self.env.configure_reset(abi.RESET_RANDOM, randomize_params=True, gravity_rollouts=self.num_physics_rollouts)

@@ -112,6 +112,7 @@ class HipRuntime:
         # set by the randomizer wrappers before the first reset (randomizers/*.py)
         self._reset_mode = abi.RESET_FIXED
         self._randomize_params = False
+        self._gravity_rollouts = 0
         self._sim = None
         self._bad_flag, self._bad_event, self._bad_pending, self._bad_slot = None, None, [False, False], 0
         self._bad_seen = 0        # running count of clamped actions already reported
@@ -121,10 +122,11 @@ class HipRuntime:
         self._buffers = None
 
     # -- configuration hooks ----------------------------------------------------------------
-    def configure_reset(self, reset_mode: int, randomize_params: bool):
+    def configure_reset(self, reset_mode: int, randomize_params: bool, gravity_rollouts: int = 0):
         if self._sim is not None:
             raise RuntimeError("reset mode must be chosen before the first reset()")
         self._reset_mode, self._randomize_params = int(reset_mode), bool(randomize_params)
+        self._gravity_rollouts = int(gravity_rollouts)
         if reset_mode == abi.RESET_FIXED:
             self.model["gravity_z"] = -9.80665
         return self
@@ -145,7 +147,8 @@ class HipRuntime:
             o = self._opts
             spec = self.task.kernel_spec(self.model, reset_mode=self._reset_mode,
                                          randomize_params=self._randomize_params,
-                                         max_episode_steps=o["max_episode_steps"])
+                                         max_episode_steps=o["max_episode_steps"],
+                                         gravity_rollouts=self._gravity_rollouts)
             cfg = abi.config_struct(self.model, spec, num_envs=self.num_envs,
                                     dtype=abi.F64 if o["dtype"] == "f64" else abi.F32,
                                     env_offset=o["env_offset"], seed=o["seed"],

@@ -60,52 +60,58 @@ class MonopodTask:
 
     normalized = True
 
+    SUPPORTED_TASK_MODES = ("free_hip", "fixed_hip", "fixed", "fixed_hip_torque", "simple", "fixed_hip_simple")
+    REQUIRED_KWARGS = ("task_mode", "reward_class", "reset_positions")
+    ACTION_HISTORY_LEN = 10
+
     def __init__(self, agent_rate: float, **kwargs):
-        self.supported_task_modes = ["free_hip", "fixed_hip", "fixed", "fixed_hip_torque",
-                                     "simple", "fixed_hip_simple"]
-        required_kwargs = ["task_mode", "reward_class", "reset_positions"]
-        for rkwarg in required_kwargs:
-            if rkwarg not in kwargs:
-                raise RuntimeError("Missing required kwarg: " + rkwarg
-                                   + ". We require the following kwargs, " + str(required_kwargs)
-                                   + "\n in the MonopodTask class. (These can be specified in env init)")
-        if len(required_kwargs) != len(kwargs):
-            warnings.warn("# WARNING: Supplied Kwargs, " + str(kwargs)
-                          + " Contains more entries than expected. Required Kwargs are "
-                          + str(required_kwargs) + ". Could be caused by config object.",
-                          SyntaxWarning, stacklevel=2)
-        self.__dict__.update(kwargs)
-        self.cfg = kwargs.get("config") or SettingsConfig()
-        supported_reset_pos = list(self.cfg.get_config("/resets").keys())
-        if not set(self.reset_positions).issubset(set(supported_reset_pos)):
-            raise RuntimeError("One or more of the reset positions provided were not in the "
-                               "supported reset positions. " + str(supported_reset_pos))
-        if self.task_mode not in self.supported_task_modes:
-            raise RuntimeError("task mode " + self.task_mode
-                               + " not supported in monopod environment.")
-        try:
-            self.spaces_definition = self.cfg.get_config(
-                "task_modes/" + self.task_mode + "/spaces")
-        except KeyError:
-            raise RuntimeError("task mode " + self.task_mode + " does not contain spaces "
-                               "definition in monopod environment config file.")
+        """Same contract as the reference constructor (tasks/monopod.py:37-103): the three required kwargs, every
+        kwarg becomes an attribute, an optional ``config`` object replaces the packaged settings, and a bad task
+        mode / reset position / missing kwarg raises RuntimeError."""
+        self._validate_kwargs(kwargs)
         self.agent_rate = agent_rate
-        self.model_name = None
-        self.model = None
-        self.reset_space = None
-        self.action_space = None
-        self.observation_space = None
-        self.current_reset_orientation = None
-        self.np_random = np.random.default_rng()
-        self.action_names = [*self.spaces_definition["action"]]
-        self.joint_names = [*self.spaces_definition["observation"]]
+        self.supported_task_modes = list(self.SUPPORTED_TASK_MODES)
+        self.cfg = kwargs.get("config") or SettingsConfig()
+        # what the kernel's epilogue is derived from: the settings subtree of this task mode
+        self.spaces_definition = self._spaces_of(self.cfg, kwargs["task_mode"], kwargs["reset_positions"])
+        sd = self.spaces_definition
+        self.action_names = list(sd["action"])
+        self.joint_names = list(sd["observation"])
+        self.observing_measured_torque = sd["observing_measured_torque"]
+        self.observation_name_mask = sd["observation_mask"]
         self.observation_index: Dict[str, int] = {}
-        history_len = 10
-        self.action_history: Deque = deque(
-            [np.zeros(len(self.action_names)) for _ in range(history_len)], maxlen=history_len)
-        self.observing_measured_torque = self.spaces_definition["observing_measured_torque"]
-        self.observation_name_mask = self.spaces_definition["observation_mask"]
-        self.__dict__.update(kwargs)
+        # filled by create_spaces() / the runtime
+        self.action_space = self.observation_space = self.reset_space = None
+        self.model = self.model_name = self.current_reset_orientation = None
+        self.np_random = np.random.default_rng()
+        zero = np.zeros(len(self.action_names))
+        self.action_history: Deque = deque((zero.copy() for _ in range(self.ACTION_HISTORY_LEN)), maxlen=self.ACTION_HISTORY_LEN)
+        for name, value in kwargs.items():            # task_mode, reward_class, reset_positions, and any override
+            setattr(self, name, value)
+
+    @classmethod
+    def _validate_kwargs(cls, kwargs):
+        required = list(cls.REQUIRED_KWARGS)
+        missing = [k for k in required if k not in kwargs]
+        if missing:
+            raise RuntimeError("Missing required kwarg: " + missing[0] + ". We require the following kwargs, " + str(required)
+                               + "\n in the MonopodTask class. (These can be specified in env init)")
+        if len(kwargs) != len(required):
+            warnings.warn("# WARNING: Supplied Kwargs, " + str(kwargs) + " Contains more entries than expected. Required Kwargs are "
+                          + str(required) + ". Could be caused by config object.", SyntaxWarning, stacklevel=3)
+
+    @classmethod
+    def _spaces_of(cls, cfg, task_mode, reset_positions):
+        known_resets = list(cfg.get_config("/resets").keys())
+        if not set(reset_positions) <= set(known_resets):
+            raise RuntimeError("One or more of the reset positions provided were not in the supported reset positions. "
+                               + str(known_resets))
+        if task_mode not in cls.SUPPORTED_TASK_MODES:
+            raise RuntimeError("task mode " + task_mode + " not supported in monopod environment.")
+        try:
+            return cfg.get_config("task_modes/" + task_mode + "/spaces")
+        except KeyError:
+            raise RuntimeError("task mode " + task_mode + " does not contain spaces definition in monopod environment config file.")
 
     # -----------------------------------------------------------------------------
     def create_spaces(self) -> Tuple[Box, Box]:
@@ -209,7 +215,7 @@ class MonopodTask:
         return float(np.float64(low) + _EPS), float(np.float64(high) - _EPS)
 
     def kernel_spec(self, model: dict, *, reset_mode: int = abi.RESET_FIXED,
-                    randomize_params: bool = False, max_episode_steps: int = 0) -> dict:
+                    randomize_params: bool = False, max_episode_steps: int = 0, gravity_rollouts: int = 0) -> dict:
         """Flatten the task into the ``Os2rTaskSpec`` fields (see include/os2r.h)."""
         if self.observation_space is None:
             self.create_spaces()
@@ -299,4 +305,5 @@ class MonopodTask:
             "dr_damping_lo": 0.8, "dr_damping_hi": 1.2,
             "dr_mu_base": 0.33, "dr_mu_lo": 0.8, "dr_mu_hi": 1.2,
             "dr_gravity_mean": -9.8, "dr_gravity_std": 0.2 if reset_mode == abi.RESET_RANDOM else 0.0,
+            "gravity_rollouts": int(gravity_rollouts) if reset_mode == abi.RESET_RANDOM else 0,
         }

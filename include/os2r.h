@@ -140,6 +140,11 @@ typedef struct Os2rTaskSpec {
   double dr_damping_lo, dr_damping_hi;    /* coefficient, U(0.8,1.2), zeros ignored         */
   double dr_mu_base, dr_mu_lo, dr_mu_hi;  /* 0.33 * U(0.8,1.2)                              */
   double dr_gravity_mean, dr_gravity_std; /* N(-9.8,0.2), drawn once at create              */
+  int32_t gravity_rollouts;        /* > 0: gravity is drawn anew for an environment after every    */
+                                   /*   this many of its rollouts (the reference re-creates the    */
+                                   /*   simulator then: randomizers/monopod.py:36-41,56-61,371);   */
+                                   /*   0: once at create                                          */
+  int32_t reserved_;
 } Os2rTaskSpec;
 
 typedef struct Os2rConfig {

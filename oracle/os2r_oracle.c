@@ -743,6 +743,12 @@ static void reset_env(OrcSim* s, int64_t e) {
       s->mu[i * N + e] = ts->dr_mu_base * (ts->dr_mu_lo + (ts->dr_mu_hi - ts->dr_mu_lo) * b[1]);
     }
   }
+  /* randomize_physics runs when the reference re-creates its simulator, every num_physics_rollouts rollouts
+   * (randomizers/monopod.py:36-41,56-61,371): `epi` rollouts of this environment are over now */
+  if (ts->reset_mode == OS2R_RESET_RANDOM && ts->gravity_rollouts > 0 && epi > 0u && epi % (uint32_t)ts->gravity_rollouts == 0u) {
+    double z[2]; normal2(cfg->seed, genv, STREAM_GRAVITY, epi / (uint32_t)ts->gravity_rollouts, 0, z);
+    s->gravity[e] = ts->dr_gravity_mean + ts->dr_gravity_std * z[0];
+  }
   s->episode[e] = epi + 1;
 }
 

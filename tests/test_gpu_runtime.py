@@ -361,3 +361,43 @@ def test_step_can_be_captured_in_a_hip_graph(torch_mod):
     for a, b in zip(eager.get_state(), graphed.get_state()):
         assert torch_mod.equal(a, b)
     eager.close(); graphed.close()
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_path_gathers_what_a_single_handle_computes(tmp_path):
+    """The multi-rank path of bench.py as the driver launches it, on this box's one GPU: two gloo ranks share
+    the device (fresh child processes, the launcher starts before anything touches the GPU), each owns 65 536
+    environments of C4 and gathers obs / reward / done to rank 0 every step.  The line reports the whole job, and
+    what rank 0 gathered in the last step equals a single 131 072-environment handle stepped as often, bit for bit."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    dump = tmp_path / "gathered.npz"
+    env = dict(os.environ, MASTER_PORT="29533", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--gather-obs",
+           "--steps", "10", "--warmup", "2", "--preroll", "20", "--no-cpu-baseline", "--dump-gathered", str(dump)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 131072 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(131072 * 10 / (d["ms_per_step"] * 1e-3 * 10), rel=1e-6)
+    got = np.load(dump)
+    assert got["obs"].shape == (131072, 10) and int(got["steps_run"]) == 32
+    # the same job as one handle
+    import argparse
+    import bench
+    from gym_os2r_amd.sim import HipSim
+    ns = argparse.Namespace(workload="C4", envs_per_gpu=131072, dtype="f64", seed=42, pgs_iters=20, pgs_normal_iters=3,
+                            pgs_tol=1e-24, runtime_model=False)
+    cfg, _, _ = bench.build_config(ns, 0, 1)
+    sim = HipSim(cfg, device="cuda:0")
+    for _ in range(32):
+        obs, rew, done, _ = sim.step(None, want_terminal=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), got["obs"])
+    assert np.array_equal(rew.cpu().numpy(), got["reward"])
+    assert np.array_equal(done.cpu().numpy(), got["done"])
+    sim.close()

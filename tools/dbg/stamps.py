@@ -20,14 +20,14 @@ PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y
           "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "prologue (once per env-step)", "epilogue: state stores (once per env-step)",
           "  dyn: body velocities", "  dyn: inward body 4", "  dyn: inward body 3", "  dyn: inward body 2", "  dyn: inward body 1",
           "  dyn: inward body 0", "-", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)"]
-NS = 24   # kStamps in os2r_device.hpp
+NS = 26   # kStamps in os2r_device.hpp
 
 
 def main():
     class A:  # bench.build_config arguments
         workload = sys.argv[1] if len(sys.argv) > 1 else "C4"
         envs_per_gpu = 65536; dtype = "f64"; seed = 42; pgs_iters = 20; pgs_normal_iters = 3
-        pgs_tol = float(os.environ.get("OS2R_PGS_TOL", "1e-24")); runtime_model = False
+        pgs_tol = float(os.environ["OS2R_PGS_TOL"]) if "OS2R_PGS_TOL" in os.environ else None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
     from gym_os2r_amd.sim import HipSim
     sim = HipSim(cfg)
@@ -43,11 +43,18 @@ def main():
         torch.cuda.synchronize()
         per_wave = buf.cpu().numpy().reshape(nwg, NS)
         acc += per_wave.mean(axis=0)
-        tot_w = per_wave.sum(axis=1)
+        tot_w = per_wave[:, :24].sum(axis=1)
         spread = (tot_w.min(), tot_w.mean(), tot_w.max(), tot_w.std(), np.percentile(tot_w, 50), np.percentile(tot_w, 99))
     acc /= 20
+    ghz = float(np.median(per_wave[:, 24] / np.maximum(per_wave[:, 25], 1)) * 0.1)
+    acc = acc[:24]
     ms = sim.bench_steps(200) / 200
     print(f"stamp build: {ms * 1e3:.1f} us per env-step launch -> {ms * 1e6 / acc.sum():.3f} ns per tick of the stamped part")
+    print(f"in-kernel clock: {ghz:.3f} GHz (median over waves of s_memtime / s_memrealtime x 100 MHz, last of 20 stamped launches after the pre-roll)")
+    if os.environ.get("OS2R_CLOCK_JSON"):
+        import json
+        json.dump({"ghz": ghz, "note": f"{A.workload}, {cfg.num_envs} envs, median over waves, stamp build, after {sys.argv[2] if len(sys.argv) > 2 else 50} pre-roll steps"},
+                  open(os.environ["OS2R_CLOCK_JSON"], "w"))
     tot = acc.sum()
     print(f"workload {A.workload}: {tot:.0f} ticks per env-step per wave ({tot / cfg.substeps:.0f} per physics iteration)")
     print(f"per-wave ticks of the last step: min {spread[0]:.0f} mean {spread[1]:.0f} max {spread[2]:.0f} (max/mean {spread[2] / spread[1]:.3f}; std {spread[3]:.0f}, median {spread[4]:.0f}, p99 {spread[5]:.0f})")

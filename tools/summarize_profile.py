@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a tools/profile.sh output directory (rocprofv3 CSVs) into one JSON + markdown summary.
 
-Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name>
+Usage: python tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> [kernel substring] [traffic.json to write] [clock.json from tools/dbg/stamps.py]
 Counter corrections follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x (reported as-is and
 doubled, both are given; this kernel's reads are 8-byte-per-lane SoA loads, uncalibrated width).
@@ -43,8 +43,21 @@ def main():
            "counters_per_launch": c}
     if trace_rows:
         r = trace_rows[0]
-        out["launch"] = {k: r[k] for k in ("Grid_Size_X", "Workgroup_Size_X", "VGPR_Count", "Accum_VGPR_Count",
-                                            "SGPR_Count", "LDS_Block_Size", "Scratch_Size")}
+        out["launch"] = {k: r[k] for k in ("Grid_Size_X", "Workgroup_Size_X", "LDS_Block_Size", "Scratch_Size")}
+    # register allocation: from the code object of the library that ran, not from rocprofv3's VGPR_Count /
+    # Accum_VGPR_Count fields (which are not the allocation)
+    if out["kernel"]:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import kernel_meta
+        lib = os.environ.get("OS2R_LIBRARY") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gym-os2r_amd", "libos2r.so")
+        co = kernel_meta.lookup(kernel_meta.kernel_meta(lib), out["kernel"]) if os.path.exists(lib) else None
+        if co:
+            out["code_object"] = dict(co, library=os.path.basename(lib),
+                                      arch_vgprs=co["vgpr_count"] - co["agpr_count"],
+                                      waves_per_simd_by_registers=max(1, min(8, 512 // (((co["vgpr_count"] + 7) // 8) * 8))))
+    clock = sys.argv[5] if len(sys.argv) > 5 else None
+    if clock and os.path.exists(clock):
+        out["in_kernel_clock"] = json.load(open(clock))
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         out["hbm_bytes_per_launch_raw"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         out["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
@@ -60,6 +73,14 @@ def main():
             f.write(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.3f} |\n")
         if "launch" in out:
             f.write("\n## launch\n\n" + ", ".join(f"{k}={v}" for k, v in out["launch"].items()) + "\n")
+        if "code_object" in out:
+            c_ = out["code_object"]
+            f.write(f"\n## code object ({c_['library']}, AMDGPU metadata note)\n\nunified registers per lane {c_['vgpr_count']} = {c_['arch_vgprs']} VGPR + "
+                    f"{c_['agpr_count']} AGPR (-> {c_['waves_per_simd_by_registers']} wave(s) per SIMD), SGPRs {c_['sgpr_count']}, SGPR spills {c_['sgpr_spill_count']}, "
+                    f"VGPR spills {c_['vgpr_spill_count']}, scratch {c_['private_segment_fixed_size']} B/lane, LDS {c_['group_segment_fixed_size']} B/workgroup\n")
+        if "in_kernel_clock" in out:
+            k_ = out["in_kernel_clock"]
+            f.write(f"\n## in-kernel clock (diagnostic stamp build, s_memtime / s_memrealtime)\n\n{k_.get('ghz'):.3f} GHz ({k_.get('note', '')})\n")
         f.write("\n## PMC (mean per launch of the step kernel; separate passes)\n\n| counter | value |\n|---|---|\n")
         for k in sorted(c):
             f.write(f"| {k} | {c[k]:.6g} |\n")
