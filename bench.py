@@ -74,13 +74,14 @@ def build_config(args, rank, world):
 
 def algorithmic_bytes_per_env_step(cfg, esz):
     """HBM bytes one env-step must move (DESIGN.md 'Data layout'): state + per-env parameters in,
-    state + observation + reward + done out; actions are generated on device."""
+    state + observation + terminal observation + reward + done out (what a gym-level env.step asks of the launch);
+    actions are generated on device."""
     nq, D = cfg.model.nq, cfg.task.obs_dim
     dr = cfg.task.reset_mode == 1
     reads = (2 * nq + 2) * esz + 4 + 4 + 1            # q, qd, last action; step / episode counters, pose
     if dr:
         reads += (4 * nq + 1) * esz                   # mass scale, damping, friction, mu, gravity
-    writes = (2 * nq + 4) * esz + D * esz + esz + 1 + 4  # q, qd, action history x2; obs; reward; done; steps
+    writes = (2 * nq + 4) * esz + 2 * D * esz + esz + 1 + 4  # q, qd, action history x2; obs and terminal obs; reward; done; steps
     return reads + writes
 
 

@@ -42,6 +42,13 @@ def main():
            "pct_of_gpu_time": float(step["Percentage"]) if step else None,
            "counters_per_launch": c}
     if trace_rows:
+        # the bench's timed window is the last `steps` launches of the command (pre-roll and warm-up come first)
+        import numpy as np
+        dur = np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sorted(trace_rows, key=lambda r: int(r["Dispatch_Id"]))])
+        nwin = int(os.environ.get("OS2R_TIMED_STEPS", "1000"))
+        out["timed_window"] = {"launches": int(min(nwin, len(dur))), "avg_ns": float(dur[-nwin:].mean()), "min_ns": int(dur[-nwin:].min()),
+                               "max_ns": int(dur[-nwin:].max())}
+        out["avg_ns_per_100_launches"] = [float(dur[a:a + 100].mean()) for a in range(0, len(dur), 100)]
         r = trace_rows[0]
         out["launch"] = {k: r[k] for k in ("Grid_Size_X", "Workgroup_Size_X", "LDS_Block_Size", "Scratch_Size")}
     # register allocation: from the code object of the library that ran, not from rocprofv3's VGPR_Count /
@@ -71,6 +78,11 @@ def main():
         f.write("## kernel-trace --stats\n\n| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|\n")
         for r in stats:
             f.write(f"| `{r['Name']}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.3f} |\n")
+        if "timed_window" in out:
+            w_ = out["timed_window"]
+            f.write(f"\nTimed window of the command (its last {w_['launches']} launches of the step kernel; pre-roll and warm-up precede it): "
+                    f"avg {w_['avg_ns']:.0f} ns, min {w_['min_ns']}, max {w_['max_ns']}.  Average per 100 launches from the reset: "
+                    + ", ".join(f"{v / 1e3:.1f}" for v in out["avg_ns_per_100_launches"]) + " us.\n")
         if "launch" in out:
             f.write("\n## launch\n\n" + ", ".join(f"{k}={v}" for k, v in out["launch"].items()) + "\n")
         if "code_object" in out:
