@@ -188,6 +188,36 @@ struct RtModel {
   __device__ __forceinline__ T cand_radius(int b) const { return p->cand_radius[b]; }
 };
 
+// Per robot, evaluated by the compiler ONCE as a constant object: for every body the coordinate with the fewest runs
+// of equal values among its candidates, and for every candidate whether it starts a run of that coordinate.  (As
+// plain constexpr functions called with an unrolled loop index these were folded for the 32-point links of the
+// monopod but evaluated at RUN time -- dependent scalar loads of the table, a compare per point, every physics
+// iteration -- for the 40-point lumped link of monopod-fixed_hip: 58 % of an env-step of Monopod-balance-v1.)
+template <int ID>
+struct CandMeta {
+  using Tb = gen::Tables<ID>;
+  struct Data { int axis[OS2R_MAX_DOF]; bool starts[OS2R_MAX_CAND > 0 ? OS2R_MAX_CAND : 1]; };
+  static constexpr int runs(int b, int a) {
+    int n = 0;
+    for (int k = Tb::cand_begin[b]; k < Tb::cand_begin[b + 1]; ++k)
+      if (k == Tb::cand_begin[b] || Tb::cand_p[k][a] != Tb::cand_p[k - 1][a]) ++n;
+    return n;
+  }
+  static constexpr Data make() {
+    Data d{};
+    for (int b = 0; b < Tb::nq; ++b) {
+      int best = 0;
+      for (int a = 1; a < 3; ++a)
+        if (runs(b, a) < runs(b, best)) best = a;
+      d.axis[b] = best;
+      for (int k = Tb::cand_begin[b]; k < Tb::cand_begin[b + 1]; ++k)
+        d.starts[k] = k == Tb::cand_begin[b] || Tb::cand_p[k][best] != Tb::cand_p[k - 1][best];
+    }
+    return d;
+  }
+  static constexpr Data value = make();
+};
+
 template <typename T, int ID>
 struct StModel {
   using Tb = gen::Tables<ID>;
@@ -209,24 +239,10 @@ struct StModel {
   __device__ __forceinline__ constexpr T cand(int k, int j) const { return (T)Tb::cand_p[k][j]; }
   __device__ __forceinline__ constexpr T cand_center(int b, int j) const { return (T)Tb::cand_center[b][j]; }
   __device__ __forceinline__ constexpr T cand_radius(int b) const { return (T)Tb::cand_radius[b]; }
-  // Candidate points of a link often share a coordinate (the two faces of a plate, a rim at constant height):
-  // number of runs of equal values of coordinate `a` among the link's candidates, and the coordinate with the
-  // fewest runs -- the scan evaluates that coordinate's terms once per run instead of once per point.
-  static constexpr int cand_runs(int b, int a) {
-    int n = 0;
-    for (int k = Tb::cand_begin[b]; k < Tb::cand_begin[b + 1]; ++k)
-      if (k == Tb::cand_begin[b] || Tb::cand_p[k][a] != Tb::cand_p[k - 1][a]) ++n;
-    return n;
-  }
-  static constexpr int cand_group_axis(int b) {
-    int best = 0;
-    for (int a = 1; a < 3; ++a)
-      if (cand_runs(b, a) < cand_runs(b, best)) best = a;
-    return best;
-  }
-  static constexpr bool cand_starts_run(int b, int k, int a) {
-    return k == Tb::cand_begin[b] || Tb::cand_p[k][a] != Tb::cand_p[k - 1][a];
-  }
+  // Candidate points of a link often share a coordinate (the two faces of a plate, a rim at constant height): the
+  // scan evaluates that coordinate's terms once per run of equal values instead of once per point (CandMeta below).
+  static constexpr int cand_group_axis(int b) { return CandMeta<ID>::value.axis[b]; }
+  static constexpr bool cand_starts_run(int /*b*/, int k, int /*a: the group axis of k's body*/) { return CandMeta<ID>::value.starts[k]; }
 };
 
 // ----------------------------------------------------------------------------------------
@@ -1178,6 +1194,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // skips a group once none of its lanes is live, and a lane's result does not depend on the other lanes).
   // With pgs_tol == 0 only an exact fixed point stops an environment, which changes nothing: every further
   // sweep would reproduce the state bit for bit.
+  // the tolerance in a vector register for the whole solve: as a kernel argument it is re-fetched from the argument
+  // segment (a scalar load and a wait of ~150 cycles that nothing covers) at every check
+  T tol_v = pgs_tol;
+  asm volatile("" : "+v"(tol_v));
   auto grouped_sweeps = [&](auto coupled, auto first) {
     constexpr int kFirst = decltype(first)::value;
     bool live = true;
@@ -1203,7 +1223,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         if (check) {
           moved = T(0);
           sweep(coupled, first, std::true_type{});
-          live = moved > pgs_tol;
+          live = moved > tol_v;
         } else {
           sweep(coupled, first, std::false_type{});
         }
