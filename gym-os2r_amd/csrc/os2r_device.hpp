@@ -579,12 +579,15 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // ---- 1. sin/cos of the joint angles; rotations are rebuilt from them where needed ----
   // The first iteration of an env-step evaluates them; the later ones turn (sin, cos) by the angle the
   // joint moved in the previous iteration, d = dt * qd (exactly the increment the integrator applied), with
-  // sin d and cos d - 1 from their series (|d| < 0.01: truncation below 1e-20): 15 instructions per joint
-  // instead of ~45, rounding ~1 ulp per turn, refreshed every env-step.
+  // sin d and cos d - 1 from their series (|d| < 0.06, i.e. |qd| < 600 rad/s at dt = 1e-4, beyond the velocity at
+  // which an episode ends: truncation below 2e-20): 19 instructions per joint instead of ~45, rounding ~1 ulp per
+  // turn, refreshed every env-step.  (Up to round 2 the bound was 0.01 with two terms fewer: without ground contact
+  // the free leg spins at 100-370 rad/s and most lanes fell back to the full evaluation -- with both paths executed
+  // by a wave whose lanes disagree, 13 % of an env-step of C2.)
   {
     bool ok = true, small = !first_iteration;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) { ok = ok && sincos_in_range(q[i]); small = small && fabs_t(dt * qd[i]) < T(0.01); }
+    for (int i = 0; i < NQ; ++i) { ok = ok && sincos_in_range(q[i]); small = small && fabs_t(dt * qd[i]) < T(0.06); }
     // The choice is made per lane (divergent branches; a wave whose lanes agree, the usual case, executes one
     // side only): what a lane computes must not depend on who shares its wave.
     if constexpr (COUNT) wc.full_sincos += __ballot(!small) != 0ull ? 1u : 0u;
@@ -592,10 +595,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
         const T d = dt * qd[i], z = d * d;
-        T p = fma_t(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
+        T p = fma_t(z, T(-1.0 / 39916800.0), T(1.0 / 362880.0));
+        p = fma_t(z, p, T(-1.0 / 5040.0));
+        p = fma_t(z, p, T(1.0 / 120.0));
         p = fma_t(z, p, T(-1.0 / 6.0));
         const T sd = fma_t(d * z, p, d);
-        T r = fma_t(z, T(-1.0 / 720.0), T(1.0 / 24.0));
+        T r = fma_t(z, T(-1.0 / 3628800.0), T(1.0 / 40320.0));
+        r = fma_t(z, r, T(-1.0 / 720.0));
+        r = fma_t(z, r, T(1.0 / 24.0));
         r = fma_t(z, r, T(-0.5));
         const T cm = z * r;
         const T s0 = sn[i], c0 = cs[i];

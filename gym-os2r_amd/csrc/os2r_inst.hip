@@ -20,7 +20,7 @@ using T = OS2R_REAL;
 
 // Observation layouts of the reference's task modes on this unit's robot (tasks/monopod.py:105-200 evaluated
 // on models/config/default/settings.yaml; {kind OS2R_OBS_*, source dof} per slot): the step kernel exists with
-// each of them folded in (contact on, default sweep counts); any other layout runs the generic one.
+// each of them folded in (default sweep counts); any other layout runs the generic one.
 #define OS2R_LAYOUT(NAME, D, ...)                                                                   \
   struct NAME##_t { static constexpr int k[D][2] = {__VA_ARGS__}; };                                 \
   constexpr unsigned long long NAME##_pack(int col) {                                                \
@@ -56,9 +56,9 @@ static int launch_step(const StepArgs<T>& a, hipStream_t s) {
   // the compiled-in robots also exist with the default sweep counts as compile-time loop bounds
   if (MD::kStatic && a.pgs_iters == kStdPgsIters && a.pgs_normal_iters == kStdPgsNormalIters) {
 #if OS2R_UNIT < 10
-    if constexpr (CONTACT) {
+    {
       if (layout_is<LayA>(a)) {
-        if constexpr (kHaveCounting) {
+        if constexpr (kHaveCounting && CONTACT) {
           if (a.counters) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayA, true>), grid, block, 0, s, a); return 0; }
         }
         if (a.counters) return 1;
@@ -67,7 +67,7 @@ static int launch_step(const StepArgs<T>& a, hipStream_t s) {
       }
 #if OS2R_UNIT == 1
       if (layout_is<LayB>(a)) {
-        if constexpr (kHaveCounting) {
+        if constexpr (kHaveCounting && CONTACT) {
           if (a.counters) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, MD::kStatic, LayB, true>), grid, block, 0, s, a); return 0; }
         }
         if (a.counters) return 1;

@@ -26,7 +26,7 @@ NS = 26   # kStamps in os2r_device.hpp
 def main():
     class A:  # bench.build_config arguments
         workload = sys.argv[1] if len(sys.argv) > 1 else "C4"
-        envs_per_gpu = 65536; dtype = "f64"; seed = 42; pgs_iters = 20; pgs_normal_iters = 3
+        envs_per_gpu = int(os.environ.get("OS2R_ENVS", "65536")); dtype = "f64"; seed = 42; pgs_iters = 20; pgs_normal_iters = 3
         pgs_tol = float(os.environ["OS2R_PGS_TOL"]) if "OS2R_PGS_TOL" in os.environ else None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
     from gym_os2r_amd.sim import HipSim
