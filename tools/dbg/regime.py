@@ -1,5 +1,8 @@
+"""Diagnostic: launch time and termination rate per 100 env-steps from the reset, for V1 and C4 -- shows where the
+rollout becomes stationary (what bench.py --preroll is for)."""
 import sys, argparse, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from gym_os2r_amd.sim import HipSim
 for wl in ("V1", "C4"):
