@@ -556,6 +556,79 @@ static int build_problem(const Os2rConfig* cfg, int contact_model, const EnvPara
  * environment stops sweeping when that is <= tol.  tol == 0 stops at exact fixed points only, which
  * changes nothing (every further sweep would reproduce the state bit for bit). */
 #define ORC_PGS_GROUP 4
+/* EXPERIMENT (oracle only, off by default; DESIGN.md 3.2 "convergence study"): in phase 2 the three rows of a
+ * contact are minimised over exactly as a block (enumeration of the active sets of the 3-variable box QP, first
+ * assignment that meets the optimality conditions) instead of row by row.  Measures what an exact per-contact
+ * block would buy in closed loop before anything of the kind is built for the GPU. */
+static int g_block_solve = 0;
+void orc_set_experimental_block_solve(int on) { g_block_solve = on; }
+
+static int solve_sub(const double A[3][3], const double c[3], const int* idx, int m, double* mu) {
+  /* A_FF mu_F = -c_F for the m free variables idx[0..m) by Cramer's rule; 0 if singular */
+  if (m == 0) return 1;
+  if (m == 1) { const int i = idx[0]; if (!(A[i][i] > 0.0)) return 0; mu[i] = -c[i] / A[i][i]; return 1; }
+  if (m == 2) {
+    const int i = idx[0], j = idx[1];
+    const double det = A[i][i] * A[j][j] - A[i][j] * A[i][j];
+    if (!(det > 1e-14 * A[i][i] * A[j][j])) return 0;
+    mu[i] = -(A[j][j] * c[i] - A[i][j] * c[j]) / det;
+    mu[j] = -(A[i][i] * c[j] - A[i][j] * c[i]) / det;
+    return 1;
+  }
+  const double a = A[0][0], b = A[0][1], cc = A[0][2], d = A[1][1], e = A[1][2], f = A[2][2];
+  const double co00 = d * f - e * e, co01 = cc * e - b * f, co02 = b * e - cc * d;
+  const double det = a * co00 + b * co01 + cc * co02;
+  if (!(det > 1e-14 * a * d * f)) return 0;
+  const double co11 = a * f - cc * cc, co12 = b * cc - a * e, co22 = a * d - b * b;
+  mu[0] = -(co00 * c[0] + co01 * c[1] + co02 * c[2]) / det;
+  mu[1] = -(co01 * c[0] + co11 * c[1] + co12 * c[2]) / det;
+  mu[2] = -(co02 * c[0] + co12 * c[1] + co22 * c[2]) / det;
+  return 1;
+}
+
+/* exact block update of rows r0 (normal), r0+1, r0+2 (tangential, fixed box); returns 0 if it declined */
+static int block_update(int n, Row* rows, int r0, double* v, double* moved) {
+  Row* R[3] = {&rows[r0], &rows[r0 + 1], &rows[r0 + 2]};
+  for (int i = 0; i < 3; ++i) if (!(R[i]->d > 0.0)) return 0;
+  double A[3][3], w[3], lam[3], c[3], lo[3], hi[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += R[i]->J[k] * R[j]->T[k]; A[i][j] = s; }
+    double s = -R[i]->target; for (int k = 0; k < n; ++k) s += R[i]->J[k] * v[k];
+    w[i] = s; lam[i] = R[i]->lambda;
+  }
+  lo[0] = 0.0; hi[0] = INFINITY;
+  for (int i = 1; i < 3; ++i) { hi[i] = R[i]->bound; lo[i] = -hi[i]; }
+  for (int i = 0; i < 3; ++i) { c[i] = w[i]; for (int j = 0; j < 3; ++j) c[i] -= A[i][j] * lam[j]; }
+  double best_mu[3] = {lam[0], lam[1], lam[2]}; int found = 0;
+  for (int code = 0; code < 27 && !found; ++code) {
+    int st[3] = {code % 3, (code / 3) % 3, code / 9};            /* 0 free, 1 lower, 2 upper */
+    int ok = 1, idx[3], m = 0; double mu[3], cf[3];
+    for (int i = 0; i < 3; ++i) {
+      if (st[i] == 2 && !isfinite(hi[i])) ok = 0;
+      if (hi[i] - lo[i] <= 0.0 && st[i] != 1) ok = 0;             /* pinned variable: one state only */
+      if (st[i] == 0) idx[m++] = i; else mu[i] = st[i] == 1 ? lo[i] : hi[i];
+    }
+    if (!ok) continue;
+    for (int i = 0; i < 3; ++i) { cf[i] = c[i]; for (int j = 0; j < 3; ++j) if (st[j] != 0) cf[i] += A[i][j] * mu[j]; }
+    if (!solve_sub(A, cf, idx, m, mu)) continue;
+    for (int i = 0; i < 3 && ok; ++i) {
+      double g = c[i]; for (int j = 0; j < 3; ++j) g += A[i][j] * mu[j];
+      const double tolg = 1e-12 * sqrt(A[i][i]) * (fabs(w[0]) / sqrt(A[0][0]) + fabs(w[1]) / sqrt(A[1][1]) + fabs(w[2]) / sqrt(A[2][2]) + 1e-300);
+      if (st[i] == 0) { if (mu[i] < lo[i] || mu[i] > hi[i]) ok = 0; }
+      else if (hi[i] - lo[i] > 0.0) { if (st[i] == 1 ? g < -tolg : g > tolg) ok = 0; }
+    }
+    if (ok) { found = 1; for (int i = 0; i < 3; ++i) best_mu[i] = mu[i]; }
+  }
+  if (!found) return 0;
+  for (int i = 0; i < 3; ++i) {
+    const double dl = best_mu[i] - lam[i];
+    R[i]->lambda = best_mu[i];
+    *moved += fabs(w[i]) * fabs(dl);
+    for (int k = 0; k < n; ++k) v[k] += R[i]->T[k] * dl;
+  }
+  return 1;
+}
+
 static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, double* v) {
   for (int phase = 0; phase < 2; ++phase) {
     const int sweeps = phase == 0 ? normal_iters : iters;
@@ -565,6 +638,8 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       double moved = 0.0;
       for (int r = 0; r < nr; ++r) {
         Row* R = &rows[r];
+        if (g_block_solve && phase == 1 && normal_iters > 0 && R->kind == 0 && r + 2 < nr && rows[r + 1].kind == 1 &&
+            rows[r + 2].kind == 1 && block_update(n, rows, r, v, &moved)) { r += 2; continue; }
         if (!(R->d > 0.0)) continue;
         if (phase == 0 && R->kind == 1) continue;
         double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
