@@ -4,6 +4,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 import warnings
 
 import numpy as np
@@ -387,3 +388,33 @@ def test_gravity_is_drawn_anew_after_num_physics_rollouts(oracle):
     from gym_os2r_amd.randomizers.monopod import MonopodEnvRandomizer
     with pytest.raises(ValueError):
         MonopodEnvRandomizer(env=lambda: None, num_physics_rollouts=-1)
+
+
+def test_code_objects_of_the_built_library_have_no_scratch_and_no_runtime_tables():
+    """Guards two regressions that cost a factor of two each before they were seen in the ISA:
+    (1) scratch: every compiled-in step kernel (fp64 and fp32) runs out of registers and LDS only; the fp32 ones fit two
+        waves per SIMD (<= 256 unified registers);
+    (2) the robots' constexpr tables are folded into the instruction stream: a code object that still carries a
+        `gen::Tables<..>` data symbol reads a table at run time (as `cand_group_axis` did for the 40-point link of
+        monopod-fixed_hip: 58 % of an env-step of Monopod-balance-v1).
+    Read from the gfx950 code objects inside libos2r.so (tools/kernel_meta.py); no GPU needed."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    from gym_os2r_amd import _lib
+    meta = kernel_meta.kernel_meta(_lib.LIB_PATH)
+    static = {k: v for k, v in meta.items() if "step_kernel<" in k and "StModel<" in k}
+    assert len(static) >= 48                                    # 4 robots x 2 dtypes x (contact, DR, sweeps, layout) variants
+    for name, m in static.items():
+        assert m["private_segment_fixed_size"] == 0, (name, m)      # (spills into AGPRs are counted in vgpr_spill_count; they are not scratch)
+        if "step_kernel<float" in name:
+            assert m["vgpr_count"] <= 256, (name, m["vgpr_count"])
+    tables = []
+    for co in kernel_meta.code_objects(_lib.LIB_PATH):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            out = subprocess.run([os.path.join(kernel_meta.LLVM, "llvm-readelf"), "--symbols", f.name], capture_output=True, text=True).stdout
+        tables += [ln.split()[-1] for ln in out.splitlines() if "Tables" in ln and "OBJECT" in ln]
+    assert not tables, sorted(set(tables))[:5]
