@@ -522,6 +522,11 @@ constexpr int kPinDs = 0x1 | 0x2 | 0x4 | 0x8 | 0x10 | 0x20 | 0x40 | 0x400;
 __device__ __forceinline__ double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
 
+// One of three values by a wave-uniform index.  With a compile-time index it folds to the value; with a run-time one
+// (the generic kernels: the joint axis is data) it stays two selects -- indexing a local array with it would put
+// the array in scratch memory (88-176 B per lane in the run-time-model kernels up to round 2).
+template <typename T> __device__ __forceinline__ T pick3(int k, T a, T b, T c) { return k == 0 ? a : (k == 1 ? b : c); }
+
 // R_i = Rfix_i * Rot(axis_i, q_i): child orientation in its parent, from (sin q_i, cos q_i)
 template <typename T, typename MD>
 __device__ __forceinline__ void joint_rotation(const MD& md, int i, T s_, T c_, T (&R)[9]) {
@@ -533,9 +538,9 @@ __device__ __forceinline__ void joint_rotation(const MD& md, int i, T s_, T c_, 
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const T fa = md.rfix(i, 3 * r + ca), fb = md.rfix(i, 3 * r + cb);
-    R[3 * r + ax] = md.rfix(i, 3 * r + ax);
-    R[3 * r + ca] = c * fa + s * fb;
-    R[3 * r + cb] = c * fb - s * fa;
+    const T keep = md.rfix(i, 3 * r + ax), va = c * fa + s * fb, vb = c * fb - s * fa;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[3 * r + j] = j == ax ? keep : (j == ca ? va : vb);
   }
 }
 
@@ -698,9 +703,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         pAf = pAf + pf;
       }
       // U = I^A S : column `ax` of [[A],[H^T]]
-      const T Afull[9] = {I.A[0], I.A[1], I.A[2], I.A[1], I.A[3], I.A[4], I.A[2], I.A[4], I.A[5]};
-      const V3<T> Ua = mk(Afull[ax], Afull[3 + ax], Afull[6 + ax]);
-      const V3<T> Ul = mk(I.H[3 * ax], I.H[3 * ax + 1], I.H[3 * ax + 2]);
+      const V3<T> Ua = mk(pick3(ax, I.A[0], I.A[1], I.A[2]), pick3(ax, I.A[1], I.A[3], I.A[4]), pick3(ax, I.A[2], I.A[4], I.A[5]));
+      const V3<T> Ul = mk(pick3(ax, I.H[0], I.H[3], I.H[6]), pick3(ax, I.H[1], I.H[4], I.H[7]), pick3(ax, I.H[2], I.H[5], I.H[8]));
       const T D = comp(Ua, ax) + dt * damp;
       const T Dinv = rcp_t(D);
       T tau = T(0);
@@ -945,7 +949,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         for (int k = 0; k < 9; ++k) Rw[k] = n[k];
       }
       const int ax = md.axis(b);
-      aw[b] = mk(Rw[ax], Rw[3 + ax], Rw[6 + ax]);
+      aw[b] = mk(pick3(ax, Rw[0], Rw[1], Rw[2]), pick3(ax, Rw[3], Rw[4], Rw[5]), pick3(ax, Rw[6], Rw[7], Rw[8]));
       jo[b] = mk(ow[0], ow[1], ow[2]);
       if (!((CMASK >> b) & 1u)) continue;
       OS2R_STAMP(4);
