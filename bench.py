@@ -128,7 +128,7 @@ def load_json(name):
     return None
 
 
-def counted_flops(sim, ck, steps, dr, workload):
+def counted_flops(sim, ck, steps, dr, workload, skip=0):
     """Replay the timed window from its checkpoint with the counting kernel variant: the work the timed
     launches did (the rollout is deterministic), priced with profiles/flop_model.json.  -> dict or None."""
     from gym_os2r_amd import abi
@@ -142,6 +142,8 @@ def counted_flops(sim, ck, steps, dr, workload):
                 sim.set_params(f, v)
         sim.set_episode_info(ck["steps"], ck["episode"], ck["pose"])
         sim.step_count = ck["step_count"]
+        if skip:
+            sim.bench_steps(skip)                     # the untimed steps that lay between the checkpoint and the window
         sim.count_work(True)
         sim.bench_steps(steps)
         c = sim.work_counters()
@@ -244,7 +246,20 @@ def main():
     if args.warmup > 0:
         sim.bench_steps(args.warmup)
     count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64"
-    ck = sim.checkpoint() if count else None          # start of the timed window, for the counting replay
+    for _ in range(3 if use_dist else 0):
+        barrier()                                     # communicator set-up and first-use costs of the barrier itself stay outside
+    ck = sim.checkpoint() if count else None          # for the counting replay of the timed window
+    busy_steps = 40 if use_dist else 0                # untimed steps between the checkpoint and the window (below)
+    if use_dist:
+        # The opening barrier blocks the host for 150-400 us under RCCL; a GPU that idles through it has dropped its clock
+        # and the first launches of a short timed window run 6 % slow (measured: 145.6 against 137.9 us per launch over 20
+        # steps).  A few more untimed steps are therefore in flight while the host sits in the barrier: the device is busy
+        # until the synchronize that ends the bracket.
+        import torch as _t
+        keep = [_t.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device), _t.empty(args.envs_per_gpu, dtype=sim.dtype, device=sim.device),
+                _t.empty(args.envs_per_gpu, dtype=_t.uint8, device=sim.device), _t.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device)]
+        for _ in range(busy_steps):
+            sim.step_into(None, keep[0], keep[1], keep[2], keep[3])
     barrier()
     t0 = time.perf_counter()
     if not args.gather_obs:
@@ -261,12 +276,17 @@ def main():
             gathered = [gather_to_rank0(t.cpu() if host else t, args.envs_per_gpu * world) for t in (obs, rew, done)]
             ev1.synchronize()
             kernel_ms += ev0.elapsed_time(ev1)
-    barrier()
+    # closing bracket: this rank's K steps are over when its device has drained; the clock is read there, then the
+    # ranks meet at the barrier, and the MAX over ranks of the elapsed times below is when the slowest rank was done.
+    # (Reading the clock behind the barrier would add the collective's own latency -- 150-400 us under RCCL, 5-10 % of
+    # a 20-step window -- to a path that has no collective.)
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
     if args.gather_obs and args.dump_gathered and rank == 0:
         import numpy as np
         np.savez(args.dump_gathered, obs=gathered[0].cpu().numpy(), reward=gathered[1].cpu().numpy(), done=gathered[2].cpu().numpy(),
-                 steps_run=args.preroll + args.warmup + args.steps)
+                 steps_run=args.preroll + args.warmup + busy_steps + args.steps)
     if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -301,7 +321,7 @@ def main():
                          "note": "ALU-bound path: see roofline_valu"},
         }
         peak = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
-        cf = counted_flops(sim, ck, args.steps, WORKLOADS[args.workload][3], args.workload) if count else None
+        cf = counted_flops(sim, ck, args.steps, WORKLOADS[args.workload][3], args.workload, skip=busy_steps) if count else None
         if cf and "flops_per_launch" in cf:
             tf = cf["flops_per_launch"] / per_launch_s / 1e12
             out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": tf, "peak": peak, "unit": "TFLOP/s",

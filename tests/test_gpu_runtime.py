@@ -385,7 +385,8 @@ def test_two_rank_bench_path_gathers_what_a_single_handle_computes(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 131072 and d["scaling"] == "weak"
     assert d["value"] == pytest.approx(131072 * 10 / (d["ms_per_step"] * 1e-3 * 10), rel=1e-6)
     got = np.load(dump)
-    assert got["obs"].shape == (131072, 10) and int(got["steps_run"]) == 32
+    steps_run = int(got["steps_run"])                   # pre-roll + warm-up + the untimed steps that keep the GPU busy through the barrier + timed
+    assert got["obs"].shape == (131072, 10) and steps_run >= 32
     # the same job as one handle
     import argparse
     import bench
@@ -394,7 +395,7 @@ def test_two_rank_bench_path_gathers_what_a_single_handle_computes(tmp_path):
                             pgs_tol=1e-24, runtime_model=False)
     cfg, _, _ = bench.build_config(ns, 0, 1)
     sim = HipSim(cfg, device="cuda:0")
-    for _ in range(32):
+    for _ in range(steps_run):
         obs, rew, done, _ = sim.step(None, want_terminal=False)
     torch.cuda.synchronize()
     assert np.array_equal(obs.cpu().numpy(), got["obs"])
