@@ -249,17 +249,15 @@ def main():
     for _ in range(3 if use_dist else 0):
         barrier()                                     # communicator set-up and first-use costs of the barrier itself stay outside
     ck = sim.checkpoint() if count else None          # for the counting replay of the timed window
-    busy_steps = 40 if use_dist else 0                # untimed steps between the checkpoint and the window (below)
-    if use_dist:
-        # The opening barrier blocks the host for 150-400 us under RCCL; a GPU that idles through it has dropped its clock
-        # and the first launches of a short timed window run 6 % slow (measured: 145.6 against 137.9 us per launch over 20
-        # steps).  A few more untimed steps are therefore in flight while the host sits in the barrier: the device is busy
-        # until the synchronize that ends the bracket.
-        import torch as _t
-        keep = [_t.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device), _t.empty(args.envs_per_gpu, dtype=sim.dtype, device=sim.device),
-                _t.empty(args.envs_per_gpu, dtype=_t.uint8, device=sim.device), _t.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device)]
-        for _ in range(busy_steps):
-            sim.step_into(None, keep[0], keep[1], keep[2], keep[3])
+    # A GPU that idles just before the window -- through the checkpoint's small copies, or while the host sits in the
+    # opening barrier (150-400 us under RCCL) -- has dropped its clock, and the first launches of a short timed window run
+    # up to 6 % slow (measured: 145.6 against 137.9 us per launch over 20 steps behind an RCCL barrier).  So a few more
+    # untimed steps are in flight from here until the synchronize that ends the opening bracket.
+    busy_steps = 40
+    keep = [torch.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device), torch.empty(args.envs_per_gpu, dtype=sim.dtype, device=sim.device),
+            torch.empty(args.envs_per_gpu, dtype=torch.uint8, device=sim.device), torch.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device)]
+    for _ in range(busy_steps):
+        sim.step_into(None, keep[0], keep[1], keep[2], keep[3])
     barrier()
     t0 = time.perf_counter()
     if not args.gather_obs:
