@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Convergence studies of the contact solver behind DESIGN.md 3.2 / 5 (CPU only: the oracle and numpy).
+
+  python tests/diag/solver_study.py problems   [--regime bench|balancing]   per-problem studies on exported LCPs
+  python tests/diag/solver_study.py closedloop [--mode free_hip --dr 1 --steps 1000]   trajectory truncation
+
+`problems` exports the boxed LCP of ~2000 physics iterations of the chosen regime (oracle_py.contact_problem, states
+taken a random number of iterations into an env-step) and reports, against a 20 000-sweep solve of the same fixed-box
+problem: sweeps needed to 1e-10 by number of active normal impulses; the stopping rule's stop histogram, the sweeps
+the slowest of 64 random environments needs (what a wave runs) and the deviation from the fixed 20 sweeps; row
+orderings; joint rows every 2nd / 4th sweep; per-contact block Gauss-Seidel with k inner iterations (k = 40: exact
+blocks); a stagnation rule; the anatomy of the slowest problems (correlations of the rows in the whitened metric,
+exact active set by enumeration, spectral radius of Gauss-Seidel on the final free set).
+
+`closedloop` runs 64 environments of the balancing regime (posture PD + noise, closed loop) with several solver
+settings against a 3 + 2000-sweep solve and prints the relative state deviation every 200 env-steps; includes the
+oracle's experimental exact per-contact block solve.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import make_config            # noqa: E402
+from gym_os2r_amd import abi               # noqa: E402
+from oracle import oracle_py as O          # noqa: E402
+import lcp_ref                             # noqa: E402
+
+
+def pd_policy(q, qd, q0, ih, ik, noise, kp=8.0, kd=0.15):
+    th = -kp * (q[ih] - q0[ih]) - kd * qd[ih]
+    tk = -kp * (q[ik] - q0[ik]) - kd * qd[ik]
+    return np.clip(np.stack([th, tk], axis=1) / 2.5 + noise, -1.0, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# problem export
+# ------------------------------------------------------------------------------------------------------------------
+def collect(regime, seed=42):
+    rng = np.random.default_rng(0)
+    probs = []
+    if regime == "bench":
+        n = 512
+        cfg, task, model = make_config("free_hip", num_envs=n, reset_mode=abi.RESET_RANDOM, randomize_params=True,
+                                       max_episode_steps=100000, seed=seed, contact=True)
+        o = O.OracleSim(cfg, threads=8)
+        for k in range(1200):
+            o.step(None)
+            if k >= 300 and k % 100 == 0:
+                q, qd = o.get_state()
+                P = [o.get_params(f) for f in range(5)]
+                for e in range(0, n, 2):
+                    a = rng.uniform(-1, 1, 2) * 2.5
+                    qq, vv = q[:, e].copy(), qd[:, e].copy()
+                    for _ in range(rng.integers(0, 10)):
+                        qq, vv = O.substep(cfg, qq, vv, a, P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e])
+                    probs.append(O.contact_problem(cfg, qq, vv, a, P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e]))
+    else:
+        n = 64
+        cfg, task, model = make_config("free_hip", "BalancingV2", True, num_envs=n, contact=True, auto_reset=False, seed=seed,
+                                       reset_mode=abi.RESET_RANDOM, randomize_params=True)
+        o = O.OracleSim(cfg, threads=8)
+        ih, ik = model["act_dof"]
+        q0, _ = o.get_state()
+        prng = np.random.default_rng(2)
+        for t in range(600):
+            q, qd = o.get_state()
+            a = pd_policy(q, qd, q0, ih, ik, 0.1 * prng.uniform(-1, 1, (n, 2)))
+            if t >= 100 and t % 50 == 0:
+                P = [o.get_params(f) for f in range(5)]
+                for e in range(n):
+                    qq, vv = q[:, e].copy(), qd[:, e].copy()
+                    for _ in range(rng.integers(0, 10)):
+                        qq, vv = O.substep(cfg, qq, vv, a[e] * 2.5, P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e])
+                    probs.append(O.contact_problem(cfg, qq, vv, a[e] * 2.5, P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e]))
+            o.step(a)
+    return probs
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# vectorised Gauss-Seidel over problems with the same row count
+# ------------------------------------------------------------------------------------------------------------------
+def stack(ps):
+    J = np.stack([p["J"] for p in ps])
+    minv = np.stack([p["minv"] for p in ps])
+    T = np.einsum("pij,prj->pri", minv, J)
+    return dict(J=J, T=T, d=np.einsum("prj,prj->pr", J, T), target=np.stack([p["target"] for p in ps]), kind=ps[0]["kind"],
+                nrow=ps[0]["normal_row"], bound=np.stack([p["bound"] for p in ps]), v0=np.stack([p["vstar"] for p in ps]))
+
+
+def row_update(S, r, v, lam, lo, hi):
+    d = S["d"][:, r]
+    ok = d > 0
+    res = np.einsum("pj,pj->p", S["J"][:, r], v) - S["target"][:, r]
+    new = np.minimum(np.maximum(lam[:, r] - np.where(ok, res / np.where(ok, d, 1), 0), lo), hi)
+    dl = np.where(ok, new - lam[:, r], 0)
+    lam[:, r] += dl
+    v += S["T"][:, r] * dl[:, None]
+    return np.abs(res * dl)
+
+
+def bounds(S, box, r):
+    return (0.0, np.inf) if S["kind"][r] == 0 else (-box[:, r], box[:, r])
+
+
+def phase1(S, sweeps=3):
+    P, nr = S["d"].shape
+    v, lam = S["v0"].copy(), np.zeros((P, nr))
+    for _ in range(sweeps):
+        for r in range(nr):
+            if S["kind"][r] != 1:
+                row_update(S, r, v, lam, *((0.0, np.inf) if S["kind"][r] == 0 else (-S["bound"][:, r], S["bound"][:, r])))
+    box = S["bound"].copy()
+    for r in range(nr):
+        if S["kind"][r] == 1:
+            box[:, r] = S["bound"][:, r] * lam[:, S["nrow"][r]]
+    return v, lam, box
+
+
+def sweep(S, v, lam, box, rows=None):
+    E = np.zeros(len(v))
+    for r in (range(S["d"].shape[1]) if rows is None else rows):
+        E += row_update(S, r, v, lam, *bounds(S, box, r))
+    return E
+
+
+def block_sweep(S, v, lam, box, kin):
+    """per contact a 3x3 block with `kin` inner Gauss-Seidel iterations in impulse space, then the joint rows"""
+    nr = S["d"].shape[1]
+    for c in range((nr - 5) // 3):
+        rows = [3 * c, 3 * c + 1, 3 * c + 2]
+        Jb, Tb = S["J"][:, rows], S["T"][:, rows]
+        A = np.einsum("pij,pkj->pik", Jb, Tb)
+        w = np.einsum("pij,pj->pi", Jb, v) - S["target"][:, rows]
+        l0 = lam[:, rows].copy()
+        l_ = l0.copy()
+        for _ in range(kin):
+            for i in range(3):
+                d = A[:, i, i]
+                ok = d > 0
+                lo, hi = (0.0, np.inf) if i == 0 else (-box[:, rows[i]], box[:, rows[i]])
+                new = np.minimum(np.maximum(l_[:, i] - np.where(ok, w[:, i] / np.where(ok, d, 1), 0), lo), hi)
+                dl = np.where(ok, new - l_[:, i], 0)
+                l_[:, i] += dl
+                w += A[:, :, i] * dl[:, None]
+        lam[:, rows] = l_
+        v += np.einsum("pij,pi->pj", Tb, l_ - l0)
+    sweep(S, v, lam, box, range(nr - 5, nr))
+
+
+def err(v, vex):
+    return np.abs(v - vex).max(axis=1) / np.maximum(1.0, np.abs(vex).max(axis=1))
+
+
+def study_problems(regime):
+    probs = collect(regime)
+    groups = {}
+    for p in probs:
+        groups.setdefault(p["nr"], []).append(p)
+    print(f"{len(probs)} problems of the {regime} regime; rows per problem: {dict((k, len(v)) for k, v in sorted(groups.items()))}")
+    data = {}
+    for nr, ps in sorted(groups.items()):
+        if nr == 5:
+            continue
+        S = stack(ps)
+        v1, lam1, box = phase1(S)
+        v, lam = v1.copy(), lam1.copy()
+        for _ in range(20000):
+            sweep(S, v, lam, box)
+        data[nr] = (S, v1, lam1, box, v, (lam[:, S["kind"] == 0] > 0).sum(axis=1))
+    # 1. sweeps to 1e-10 by active normal impulses; stopping rule
+    need, act, stops, dev = [], [], [], []
+    for nr, (S, v1, lam1, box, vex, na) in data.items():
+        v, lam = v1.copy(), lam1.copy()
+        nd = np.full(len(v), 999)
+        stop = np.full(len(v), 20)
+        vfin = np.zeros_like(v)
+        done = np.zeros(len(v), bool)
+        for it in range(60):
+            E = sweep(S, v, lam, box)
+            nd = np.where((nd == 999) & (err(v, vex) < 1e-10), it + 1, nd)
+            if it < 20 and (it + 1) % 4 == 0 and it + 1 < 20:
+                newly = (E <= 1e-24) & ~done
+                stop[newly] = it + 1
+                vfin[newly] = v[newly]
+                done |= newly
+            if it == 19:
+                vfin[~done] = v[~done]
+                v20 = v.copy()
+        need.append(nd); act.append(na); stops.append(stop); dev.append(err(vfin, v20))
+    need, act, stops, dev = map(np.concatenate, (need, act, stops, dev))
+    for a in range(4):
+        m = act == a
+        if m.sum():
+            print(f"  active normal impulses {a}: {m.sum():5d} problems, sweeps to 1e-10 p50 {np.percentile(need[m], 50):.0f} p90 {np.percentile(need[m], 90):.0f} "
+                  f"p99 {np.percentile(need[m], 99):.0f} max {need[m].max()}")
+    rng = np.random.default_rng(1)
+    full = np.concatenate([stops, np.full(len(groups.get(5, [])), 4)])          # problems without contact rows stop at the first check
+    wm = np.array([full[rng.integers(0, len(full), 64)].max() for _ in range(4000)])
+    print(f"  stopping rule (1e-24 J): stop histogram at 4/8/12/16/20 sweeps {np.bincount(full, minlength=21)[[4, 8, 12, 16, 20]]}, slowest of 64: mean {wm.mean():.1f} sweeps, "
+          f"deviation from the fixed 20 sweeps max {dev.max():.1e}")
+    # 2. variants: error against the converged solve after a fixed budget
+    def run(name, fn, n=20):
+        es = []
+        for nr, (S, v1, lam1, box, vex, na) in data.items():
+            v, lam = v1.copy(), lam1.copy()
+            for it in range(n):
+                fn(S, v, lam, box, it)
+            es.append(err(v, vex))
+        e = np.concatenate(es)
+        print(f"  {name:34s} p50 {np.percentile(e, 50):.1e} p90 {np.percentile(e, 90):.1e} p99 {np.percentile(e, 99):.1e} max {e.max():.1e}")
+    print(" error against the converged solve:")
+    run("plain, 20 sweeps", lambda S, v, lam, box, it: sweep(S, v, lam, box))
+    run("plain, 16 sweeps", lambda S, v, lam, box, it: sweep(S, v, lam, box), 16)
+    run("plain, 12 sweeps", lambda S, v, lam, box, it: sweep(S, v, lam, box), 12)
+    run("reversed row order, 20", lambda S, v, lam, box, it: sweep(S, v, lam, box, range(S["d"].shape[1] - 1, -1, -1)))
+    run("symmetric (alternating order), 20", lambda S, v, lam, box, it: sweep(S, v, lam, box, range(S["d"].shape[1]) if it % 2 == 0 else range(S["d"].shape[1] - 1, -1, -1)))
+    for per in (2, 4):
+        def f(S, v, lam, box, it, per=per):
+            nr = S["d"].shape[1]
+            sweep(S, v, lam, box, range(nr - 5))
+            if (it + 1) % per == 0:
+                sweep(S, v, lam, box, range(nr - 5, nr))
+        run(f"joint rows every {per}. sweep, 20", f)
+    for kin, n in ((2, 10), (3, 8), (40, 8), (40, 4)):
+        run(f"block GS k={kin}, {n} outer sweeps", lambda S, v, lam, box, it, kin=kin: block_sweep(S, v, lam, box, kin), n)
+    # 3. anatomy of the slowest one-contact problems
+    if 8 in data:
+        S, v1, lam1, box, vex, na = data[8]
+        v, lam = v1.copy(), lam1.copy()
+        for _ in range(20):
+            sweep(S, v, lam, box)
+        e = err(v, vex)
+        np.set_printoptions(precision=3, linewidth=200)
+        for i in np.argsort(-e)[:3]:
+            p = groups[8][i]
+            A, c, lo, hi = lcp_ref.lcp_matrices(p)
+            lx, rx = lcp_ref.enumerate_exact(A, c, lo, hi)
+            st = "".join("F" if lo[r] + 1e-15 < lx[r] < hi[r] - 1e-15 else ("L" if lx[r] <= lo[r] + 1e-15 else "U") for r in range(8))
+            F = [r for r in range(8) if st[r] == "F"]
+            rho = np.abs(np.linalg.eigvals(-np.linalg.solve(np.tril(A[np.ix_(F, F)]), np.triu(A[np.ix_(F, F)], 1)))).max() if len(F) > 1 else 0.0
+            dg = np.sqrt(np.diag(A))
+            print(f"  slow problem: error at 20 sweeps {e[i]:.1e}; exact active set {st}; Gauss-Seidel spectral radius on the free set {rho:.2g}; "
+                  f"correlations n-x {A[0, 1] / dg[0] / dg[1]:+.3f} n-y {A[0, 2] / dg[0] / dg[2]:+.3f} x-y {A[1, 2] / dg[1] / dg[2]:+.3f} n-pitch friction {A[0, 4] / dg[0] / dg[4]:+.3f}")
+
+
+def study_closedloop(mode, dr, steps):
+    n = 64
+
+    def run(**kw):
+        cfg, task, model = make_config(mode, "BalancingV2", True, num_envs=n, contact=True, auto_reset=False, dtype=abi.F64, seed=42,
+                                       reset_mode=abi.RESET_RANDOM if dr else abi.RESET_FIXED, randomize_params=dr, **kw)
+        o = O.OracleSim(cfg, threads=8)
+        ih, ik = model["act_dof"]
+        q0, _ = o.get_state()
+        rng = np.random.default_rng(2)
+        traj = []
+        for t in range(steps):
+            q, qd = o.get_state()
+            o.step(pd_policy(q, qd, q0, ih, ik, 0.1 * rng.uniform(-1, 1, (n, 2))))
+            if (t + 1) % 200 == 0:
+                traj.append(np.concatenate(o.get_state()))
+        return traj
+
+    def rel(a, b):
+        return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0), axis=0)
+    ref = run(pgs_iters=2000, pgs_tol=0.0)
+    L = O.lib()
+    for name, blk, kw in [("scalar 3+20, no stopping", 0, dict(pgs_iters=20, pgs_tol=0.0)), ("scalar 3+20", 0, dict(pgs_iters=20)), ("scalar 3+16", 0, dict(pgs_iters=16)),
+                          ("scalar 3+12", 0, dict(pgs_iters=12)), ("scalar 3+8", 0, dict(pgs_iters=8)), ("scalar 3+40", 0, dict(pgs_iters=40)),
+                          ("exact blocks 3+20", 1, dict(pgs_iters=20)), ("exact blocks 3+12", 1, dict(pgs_iters=12)), ("exact blocks 3+8", 1, dict(pgs_iters=8))]:
+        L.orc_set_experimental_block_solve(blk)
+        tr = run(**kw)
+        L.orc_set_experimental_block_solve(0)
+        print(f"{name:26s} " + "  ".join(f"t={200 * (i + 1)}: med {np.median(rel(a, b)):.1e} p90 {np.percentile(rel(a, b), 90):.1e} max {rel(a, b).max():.1e}"
+                                         for i, (a, b) in enumerate(zip(tr, ref))))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["problems", "closedloop"])
+    ap.add_argument("--regime", default="bench", choices=["bench", "balancing"])
+    ap.add_argument("--mode", default="free_hip")
+    ap.add_argument("--dr", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    a = ap.parse_args()
+    O.build()
+    if a.what == "problems":
+        study_problems(a.regime)
+    else:
+        study_closedloop(a.mode, bool(a.dr), a.steps)
