@@ -629,17 +629,32 @@ static int block_update(int n, Row* rows, int r0, double* v, double* moved) {
   return 1;
 }
 
+/* EXPERIMENT (oracle only, off by default): order of the three rows of a contact inside a phase-2 sweep.
+ * 0: normal, x, y (the specification)   1: y, x, normal   2: the less mobile tangential row, the other, normal */
+static int g_row_order = 0;
+void orc_set_experimental_row_order(int order) { g_row_order = order; }
+
 static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, double* v) {
+  int order[ORC_MAX_ROWS];
+  for (int r = 0; r < nr; ++r) order[r] = r;
+  if (g_row_order != 0)
+    for (int r = 0; r + 2 < nr; ++r)
+      if (rows[r].kind == 0 && rows[r + 1].kind == 1 && rows[r + 2].kind == 1) {
+        const int y_first = g_row_order == 1 || rows[r + 2].d < rows[r + 1].d;
+        order[r] = y_first ? r + 2 : r + 1; order[r + 1] = y_first ? r + 1 : r + 2; order[r + 2] = r;
+        r += 2;
+      }
   for (int phase = 0; phase < 2; ++phase) {
     const int sweeps = phase == 0 ? normal_iters : iters;
     if (phase == 1 && normal_iters > 0)
       for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
     for (int it = 0; it < sweeps; ++it) {
       double moved = 0.0;
-      for (int r = 0; r < nr; ++r) {
+      for (int ri = 0; ri < nr; ++ri) {
+        const int r = (phase == 1 && !g_block_solve) ? order[ri] : ri;
         Row* R = &rows[r];
         if (g_block_solve && phase == 1 && normal_iters > 0 && R->kind == 0 && r + 2 < nr && rows[r + 1].kind == 1 &&
-            rows[r + 2].kind == 1 && block_update(n, rows, r, v, &moved)) { r += 2; continue; }
+            rows[r + 2].kind == 1 && block_update(n, rows, r, v, &moved)) { ri += 2; continue; }
         if (!(R->d > 0.0)) continue;
         if (phase == 0 && R->kind == 1) continue;
         double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];

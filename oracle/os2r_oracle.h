@@ -48,7 +48,8 @@ int orc_create(const Os2rConfig* cfg, OrcSim** out);
 void orc_destroy(OrcSim* s);
 void orc_set_threads(OrcSim* s, int n);
 void orc_set_contact_model(OrcSim* s, int model);
-void orc_set_experimental_block_solve(int on);   /* oracle-only experiment, see os2r_oracle.c */
+void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
+void orc_set_experimental_row_order(int order);
 int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);
 int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint8_t* done, double* term_obs);
 int orc_get_state(OrcSim* s, double* q, double* qd);
