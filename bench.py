@@ -68,7 +68,7 @@ def build_config(args, rank, world):
     n = args.envs_per_gpu
     cfg = abi.config_struct(model, spec, num_envs=n, env_offset=rank * n, seed=args.seed,
                             dtype=abi.F64 if args.dtype == "f64" else abi.F32, contact=contact,
-                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters, pgs_tol=args.pgs_tol)
+                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters, pgs_tol=args.pgs_tol, pgs_exact=args.pgs_exact)
     return cfg, model, spec
 
 
@@ -158,7 +158,9 @@ def counted_flops(sim, ck, steps, dr, workload, skip=0):
                         "phase2_sweeps_per_wave_iteration": c["sweeps"] / wi,
                         "bodies_in_contact_per_env": c["lane_contacts"] / (wi * 64.0),
                         "live_envs_per_sweep": c["live_lane_sweeps"] / max(c["sweeps"], 1),
-                        "full_sincos_per_wave_iteration": c["full_sincos"] / wi},
+                        "full_sincos_per_wave_iteration": c["full_sincos"] / wi,
+                        "exact_solves_per_wave_iteration": c["exact_solves"] / wi,
+                        "envs_per_exact_solve": c["lane_exact_solves"] / max(c["exact_solves"], 1)},
            "counters": c}
     if model:
         k = model["flops_per_unit"]
@@ -181,7 +183,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--pgs-iters", type=int, default=20)
+    ap.add_argument("--pgs-iters", type=int, default=None, help="cap on the phase-2 sweeps (default: abi.config_struct's: 12 with the exact finish, 20 without)")
+    ap.add_argument("--pgs-exact", type=int, default=None, help="exact free-set solves per physics iteration at most (default 12 in f64; 0: sweeps only, the round-2 solver)")
     ap.add_argument("--pgs-normal-iters", type=int, default=3)
     ap.add_argument("--pgs-tol", type=float, default=None,
                     help="stopping tolerance of the solver's sweeps [J] (default: 1e-24 for f64, 1e-13 for f32; 0: fixed counts)")
@@ -305,7 +308,7 @@ def main():
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}",
                        "envs_per_gpu": args.envs_per_gpu, "total_envs": total_envs, "task_mode": WORKLOADS[args.workload][0],
                        "substeps": int(cfg.substeps), "dt": float(cfg.dt), "pgs_sweeps": [int(cfg.pgs_normal_iters), int(cfg.pgs_iters)],
-                       "pgs_tol": float(cfg.pgs_tol), "preroll_steps": args.preroll,
+                       "pgs_tol": float(cfg.pgs_tol), "pgs_exact": int(cfg.pgs_exact), "preroll_steps": args.preroll,
                        "contact": bool(cfg.contact), "domain_randomisation": WORKLOADS[args.workload][3],
                        "actions": "U(-1,1) Philox on device",
                        "sharding": f"envs x{world}, " + ("obs/reward/done gathered to rank 0 every step" if args.gather_obs else "no step-path collective")},

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Mapping, Optional
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_DOF = 5
 MAX_CAND = 192
 MAX_OBS = 12
@@ -29,6 +29,9 @@ RESET_FIXED, RESET_RANDOM = 0, 1
 PARAM_MASS_SCALE, PARAM_DAMPING, PARAM_FRICTION, PARAM_MU, PARAM_GRAVITY = range(5)
 
 DONE_BIT, TRUNCATED_BIT, NONFINITE_BIT = 1, 2, 4
+
+# solver defaults (config_struct): sweeps only / with the exact finish
+DEFAULT_PGS_ITERS, DEFAULT_PGS_ITERS_EXACT, DEFAULT_PGS_EXACT = 20, 12, 12
 
 
 class Os2rModel(C.Structure):
@@ -112,6 +115,8 @@ class Os2rConfig(C.Structure):
         ("max_erv", C.c_double),
         ("contact_margin", C.c_double),
         ("pgs_tol", C.c_double),
+        ("pgs_exact", C.c_int32),
+        ("reserved0_", C.c_int32),
         ("model", Os2rModel),
         ("task", Os2rTaskSpec),
     ]
@@ -209,9 +214,14 @@ def task_struct(t: Mapping) -> Os2rTaskSpec:
 
 def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = F64,
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
-                  dt: float = 1e-4, contact: bool = True, pgs_iters: int = 20, pgs_normal_iters: int = 3,
+                  dt: float = 1e-4, contact: bool = True, pgs_iters: Optional[int] = None, pgs_normal_iters: int = 3,
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
-                  contact_margin: float = 1e-3, pgs_tol: Optional[float] = None) -> Os2rConfig:
+                  contact_margin: float = 1e-3, pgs_tol: Optional[float] = None,
+                  pgs_exact: Optional[int] = None) -> Os2rConfig:
+    """Solver defaults: fp64 -- 3 normal sweeps, then at most `pgs_iters` = 12 sweeps over all
+    rows with the exact finish (`pgs_exact` = 12 free-set solves at most per physics iteration); fp32 -- sweeps only
+    (20, checked every 4th: the exact finish needs fp64's headroom for its regularised 5 x 5 solve).  Passing
+    `pgs_exact=0, pgs_iters=20` selects the round-1/2 solver in fp64 too."""
     c = Os2rConfig()
     c.abi_version = ABI_VERSION
     c.dtype = int(dtype)
@@ -222,7 +232,12 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     c.substeps = int(substeps)
     c.dt = float(dt)
     c.contact = 1 if contact else 0
+    if pgs_exact is None:
+        pgs_exact = DEFAULT_PGS_EXACT if dtype == F64 and pgs_normal_iters > 0 else 0
+    if pgs_iters is None:
+        pgs_iters = DEFAULT_PGS_ITERS_EXACT if pgs_exact > 0 else DEFAULT_PGS_ITERS
     c.pgs_iters = int(pgs_iters)
+    c.pgs_exact = int(pgs_exact)
     c.pgs_normal_iters = int(pgs_normal_iters)
     c.auto_reset = 1 if auto_reset else 0
     c.erp = float(erp)

@@ -230,6 +230,8 @@ int validate(const Os2rConfig* c, std::string& why) {
   if (t.gravity_rollouts < 0) { why = "gravity_rollouts must be >= 0"; return 1; }
   if (c->pgs_normal_iters < 0 || c->pgs_normal_iters > 10000) { why = "pgs_normal_iters out of range"; return 1; }
   if (!(c->pgs_tol >= 0.0)) { why = "pgs_tol must be >= 0"; return 1; }
+  if (c->pgs_exact < 0 || c->pgs_exact > 10000) { why = "pgs_exact out of range"; return 1; }
+  if (c->pgs_exact > 0 && c->dtype != OS2R_F64) { why = "pgs_exact (the exact finish of the contact solve) needs dtype f64"; return 1; }
   return 0;
 }
 
@@ -246,6 +248,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.substeps = s->cfg.substeps;
   a.pgs_iters = s->cfg.pgs_iters;
   a.pgs_normal_iters = s->cfg.pgs_normal_iters;
+  a.pgs_exact = s->cfg.pgs_normal_iters > 0 ? s->cfg.pgs_exact : 0;   // the coupled pyramid has no fixed box to pivot on
   a.auto_reset = s->cfg.auto_reset;
   a.dt = (T)s->cfg.dt; a.erp = (T)s->cfg.erp; a.max_erv = (T)s->cfg.max_erv; a.margin = (T)s->cfg.contact_margin;
   a.gravity_z = (T)s->cfg.model.gravity_z;
@@ -275,7 +278,7 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
   StepArgs<T> a = make_args<T>(s);
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
   const bool contact = s->cfg.contact != 0 && s->cmask != 0u;
-  const bool std_sweeps = s->cfg.pgs_iters == kStdPgsIters && s->cfg.pgs_normal_iters == kStdPgsNormalIters;
+  const bool std_sweeps = is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact);
   hipFunction_t jit_fn = !s->jit ? nullptr
       : (std_sweeps && s->jit->fn[contact][s->dr][1]) ? s->jit->fn[contact][s->dr][1] : s->jit->fn[contact][s->dr][0];
   if (s->jit && contact && std_sweeps && s->jit->fn_layout[s->dr] && s->jit->layout_dim == a.layout_dim &&

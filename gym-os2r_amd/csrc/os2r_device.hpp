@@ -35,13 +35,25 @@
 namespace os2r {
 
 constexpr int kWave = 64;
-// the sweep counts of the default configuration: kernels built for them have compile-time loop bounds (+2 %)
-constexpr int kStdPgsIters = 20, kStdPgsNormalIters = 3;
+// the solver settings of the default configuration: kernels built for them have compile-time loop bounds (+2 %).
+// fp64: the exact finish with its lower sweep cap; fp32: sweeps only (kExact* below)
+// (kExact: the exact finish is on, with any positive cap on the solves -- the cap stays a run-time value)
+template <typename T> struct StdSolver { static constexpr int kIters = 12, kNormalIters = 3; static constexpr bool kExact = true; };
+template <> struct StdSolver<float> { static constexpr int kIters = 20, kNormalIters = 3; static constexpr bool kExact = false; };
+template <typename T> __host__ __device__ inline bool is_std_solver(int iters, int normal_iters, int exact) {
+  return iters == StdSolver<T>::kIters && normal_iters == StdSolver<T>::kNormalIters && (exact > 0) == StdSolver<T>::kExact;
+}
 // Phase-2 sweeps run in groups of kPgsGroup; the last sweep of a group measures the energy it moved
 // (sum over the rows of |residual * impulse change|, the decrease of the QP objective up to a factor <= 2) and an
 // environment whose measure is within pgs_tol stops sweeping.  Per lane: what an
 // environment computes does not depend on the company it keeps in its wave.
 constexpr int kPgsGroup = 4;
+// Exact finish of the fixed-box problem (Os2rConfig.pgs_exact > 0, fp64 only): after kExactFirst
+// sweeps an environment that has not converged solves its free rows exactly -- (S + eps I) d = -G_F^T w_F with
+// S = G_F^T G_F (NQ x NQ whatever the number of free rows), eps = kExactEps * trace S, kExactProx proximal iterations,
+// impulses from the residuals -- cuts the step at the first bound it meets, and re-tests every row with one measured sweep.
+constexpr int kExactFirst = 3, kExactProx = 3;
+constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;
 
 // Work done by one wave in one physics iteration, for the counting kernel variants (wave-uniform values).
 struct WorkCounts {
@@ -52,6 +64,8 @@ struct WorkCounts {
   unsigned lane_contacts = 0; // (lane, body) pairs in contact
   unsigned live_lane_sweeps = 0;  // phase-2 sweeps x lanes still live in them
   unsigned full_sincos = 0;   // 1 if some lane evaluated sin/cos in full in this iteration
+  unsigned exact_solves = 0;  // exact free-set solves executed (some lane of the wave needed one)
+  unsigned lane_exact_solves = 0;  // exact free-set solves x lanes that took part
 };
 
 // ----------------------------------------------------------------------------------------
@@ -127,6 +141,7 @@ struct StepArgs {
   int substeps;
   int pgs_iters;
   int pgs_normal_iters;
+  int pgs_exact;
   int auto_reset;
   T dt, erp, max_erv, margin, gravity_z;
   T pgs_tol;   // an environment stops sweeping once a checked sweep moved less energy than this (0: exact fixed points only)
@@ -397,6 +412,8 @@ __device__ __forceinline__ float rsqrt_t(float x) {
 
 __device__ __forceinline__ double fmax_t(double a, double b) { return fmax(a, b); }
 __device__ __forceinline__ float fmax_t(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double fmin_t(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float fmin_t(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fabs_t(double x) { return fabs(x); }
@@ -565,11 +582,13 @@ __device__ __forceinline__ bool for_body(int b, F&& f) {
   }
 }
 
-template <typename T, typename MD, bool CONTACT, bool DR, bool COUNT = false>
+// EXACT_ONLY: the exact finish is known to be on (pgs_exact > 0, fixed box): the grouped sweeps of the round-1/2 solver are
+// not instantiated (the kernels with the default solver settings)
+template <typename T, typename MD, bool CONTACT, bool DR, bool COUNT = false, bool EXACT_ONLY = false>
 __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& par,
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T (&sn)[MD::NQ], T (&cs)[MD::NQ], bool first_iteration,
                                         T tau_hip, T tau_knee, T dt, T erp,
-                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, T pgs_tol, T* __restrict__ lds,
+                                        T max_erv, T margin, int pgs_iters, int pgs_normal_iters, int pgs_exact, T pgs_tol, T* __restrict__ lds,
                                         const T* __restrict__ cand_lds, ModelPtr<T> mconst, WorkCounts& wc
 #ifdef OS2R_STAMPS
                                         , unsigned long long (&stamps)[kStamps], unsigned long long& stamp_prev
@@ -900,9 +919,18 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int k = 0; k < i; ++k) acc_ -= Lc[i][k] * y[k];
     y[i] = opaque(acc_ * Ldi[i]);   // a plain value for the sweeps: its product is not to be fused into their updates
   }
-  T y0[NQ];  // only the change of y is mapped back, so an idle solve leaves v bit-identical
+  // only the change of y is mapped back, so an idle solve leaves v bit-identical.  The start value waits in registers in
+  // the kernels built for the default solver settings, in per-lane LDS slots in the others (their register file is full
+  // during the exact solves, see kMuInLds below)
+  constexpr bool kParkY0 = sizeof(T) == 8 && !EXACT_ONLY;
+  constexpr int kY0Slot = NQ * (NQ + 1) / 2 + 3 * NQ + NQ;   // behind the factor's mirror and the multipliers' slots
+  static_assert(kY0Slot + NQ <= 8 * NQ, "per-lane LDS slots");
+  T y0[NQ];
 #pragma unroll
-  for (int i = 0; i < NQ; ++i) y0[i] = y[i];
+  for (int i = 0; i < NQ; ++i) {
+    if constexpr (kParkY0) L(kY0Slot + i) = y[i];
+    else y0[i] = y[i];
+  }
 
   OS2R_STAMP(3);
   // ---- 5. ground contact candidates -> one point contact per body ----
@@ -1244,6 +1272,233 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (; it + kPgsGroup < pgs_iters; it += kPgsGroup) group(kPgsGroup, true);   // a check after the last sweep would decide nothing
     group(pgs_iters - it, false);
   };
+  // ---- exact finish (fp64; kExact* above).  The rows of phase 2 in sweep order: ----
+  // f(slot, nz, g, target, lambda&, lo, hi, upper, rd): row `slot` has the non-zeros g[0..nz], an impulse in [lo, hi]
+  // (upper == false: no upper bound) and the reciprocal rd of |g|^2 (0: row off)
+  auto each_row = [&](auto first, auto&& f) {
+    constexpr int kFirst = decltype(first)::value;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+      const T lim = limfix[b];
+      f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(0), false, dn[b]);
+      f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true, dx[b]);
+      f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true, dy[b]);
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true, idj[j]);
+  };
+  // One exact solve of the rows strictly inside their box, every other row held at its bound.  Returns whether a
+  // bound cut the step short (that row then sits on its bound and the caller solves again with the smaller set).
+  // Runs under the mask of the lanes that need it; nothing in it looks at another lane.
+  auto exact_solve = [&](auto first) -> bool {
+    constexpr int NT = NQ * (NQ + 1) / 2;
+    auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };   // j <= i
+    // Branch-free on purpose (bitwise logic on the predicates, selects, min / max): written with && / || and
+    // conditional statements every row became a divergent branch of its own -- a hundred of them per solve, each a
+    // handful of scalar instructions on the execution mask plus the jump, which a lone wave pays in full.
+    auto is_free = [](T l, T lo, T hi, bool upper) { return (l > lo) & (upper ? (l < hi) : true); };
+    T S[NT], h[NQ];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) S[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) h[k] = T(0);
+    // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
+    each_row(first, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper, T) {
+      // the row's weight as a number the optimiser cannot see through: it would turn the products below back into
+      // selects of every entry (two v_cndmask per double) or into a branch around the row
+      const T f = opaque(is_free(l, lo, hi, upper) ? T(1) : T(0));
+      T w = -target;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k)
+        if (k <= nz) w = fma_t(g[k], y[k], w);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        if (i <= nz) {
+          const T gs = f * g[i];
+          h[i] = fma_t(-gs, w, h[i]);
+#pragma unroll
+          for (int j = 0; j < NQ; ++j)
+            if (j <= i) S[tri(i, j)] = fma_t(gs, g[j], S[tri(i, j)]);
+        }
+      }
+    });
+    T tr = T(0);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) tr += S[tri(i, i)];
+    const T eps = tr > T(0) ? T(kExactEps) * tr : T(1);   // no free row: S = 0 and h = 0, the step is zero
+    // S + eps I = Lf D Lf^T, natural order (symmetric positive definite: no pivoting).  Lf overwrites S (strict lower
+    // part), Di holds the reciprocal pivots.
+    T Di[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      T u[NQ];   // u[k] = Lf[j][k] D[k]: the entries of row j before their division by the pivot
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        if (k < j) {
+          T t = S[tri(j, k)];
+#pragma unroll
+          for (int m = 0; m < NQ; ++m)
+            if (m < k) t = fma_t(-S[tri(k, m)], u[m], t);
+          u[k] = t;
+        }
+      }
+      T dj = S[tri(j, j)] + eps;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        if (k < j) {
+          const T ljk = u[k] * Di[k];
+          dj = fma_t(-ljk, u[k], dj);
+          S[tri(j, k)] = ljk;
+        }
+      }
+      Di[j] = rcp_t(dj);
+    }
+    // kExactProx proximal iterations: d_1 from h, d_k from h + eps d_(k-1); ds their sum
+    T d[NQ], ds[NQ];
+#pragma unroll
+    for (int it = 0; it < kExactProx; ++it) {
+      T z[NQ];
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) z[i] = it == 0 ? h[i] : fma_t(eps, d[i], h[i]);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+          if (k < i) z[i] = fma_t(-S[tri(i, k)], z[k], z[i]);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) z[i] *= Di[i];
+#pragma unroll
+      for (int i = NQ - 1; i >= 0; --i)
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+          if (k > i) z[i] = fma_t(-S[tri(k, i)], z[k], z[i]);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) { d[i] = z[i]; ds[i] = it == 0 ? z[i] : ds[i] + z[i]; }
+    }
+    // pass 2: impulses of the free rows from the residuals, mu = -(K w + g.ds) / eps, and whether the full step
+    // would take a row out of its box
+    const T ieps = -rcp_t(eps);
+    // The multipliers wait between the passes: in registers in the kernels built for the default solver settings, in
+    // free per-lane LDS slots (behind the factor's mirror) in the others, whose register file is full -- they also
+    // carry the sweeps-only solver and, for run-time models, rows for every body (scratch otherwise: 12-370 B per lane)
+    constexpr bool kMuInLds = !EXACT_ONLY;
+    constexpr int kMuSlot = NQ * (NQ + 1) / 2;
+    static_assert(kMuSlot + 3 * NB + NQ <= 8 * NQ, "per-lane LDS slots");
+    T mu_reg[kMuInLds ? 1 : 3 * NB + NQ];
+    auto mu_put = [&](int slot, T v) { if constexpr (kMuInLds) L(kMuSlot + slot) = v; else mu_reg[slot] = v; };
+    auto mu_get = [&](int slot) -> T { if constexpr (kMuInLds) return L(kMuSlot + slot); else return mu_reg[slot]; };
+    bool cut = false;
+    each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper, T) {
+      const T f = opaque(is_free(l, lo, hi, upper) ? ieps : T(0));
+      T w = -target;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k)
+        if (k <= nz) w = fma_t(g[k], y[k], w);
+      T r = T(kExactProx) * w;
+#pragma unroll
+      for (int k = 0; k < NQ; ++k)
+        if (k <= nz) r = fma_t(g[k], ds[k], r);
+      const T m = r * f;
+      mu_put(slot, m);
+      const T full = l + m;
+      cut = cut | (full < lo) | (upper ? (full > hi) : false);
+    });
+    // the largest feasible fraction of the step: the wave computes it when one of its lanes needs it, and only the lanes
+    // whose full step leaves a box take it
+    T alpha = T(1);
+    if (__ballot(cut) != 0ull) {
+      T a = T(1);
+      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+        const T m = mu_get(slot);
+        const bool up = m > T(0);
+        const bool bounded = (m < T(0)) | (upper ? up : false);
+        const T room = (up ? hi : lo) - l;
+        const T lim = room * rcp_t(bounded ? m : T(1));   // same sign as m, so lim >= 0
+        a = (bounded & (lim < a)) ? lim : a;
+      });
+      alpha = cut ? a : T(1);
+    }
+    // the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
+    // that the cut step has taken to its bound (the room left is below kExactSnap of what it had) is set on it
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) y[i] = fma_t(alpha, d[i], y[i]);
+    if (__ballot(cut) != 0ull) {
+      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+        const T m = mu_get(slot);
+        T nl = fma_t(alpha, m, l);
+        const bool at_hi = cut & (upper ? ((m > T(0)) & ((hi - nl) <= T(kExactSnap) * (hi - l))) : false);
+        const bool at_lo = cut & (m < T(0)) & ((nl - lo) <= T(kExactSnap) * (l - lo));
+        nl = at_hi ? hi : nl;
+        nl = at_lo ? lo : nl;
+        nl = fmax_t(nl, lo);
+        if (upper) nl = fmin_t(nl, hi);
+        l = nl;
+      });
+    } else {
+      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+        T nl = l + mu_get(slot);
+        nl = fmax_t(nl, lo);
+        if (upper) nl = fmin_t(nl, hi);
+        l = nl;
+      });
+    }
+    return cut;
+  };
+  // Phase 2 with the exact finish: kExactFirst sweeps, the last of them measured; from then on an environment that is
+  // still live solves (again while a bound cuts its step short, pgs_exact solves at most per physics iteration) and
+  // takes one measured sweep, until the sweep moves no more than pgs_tol or pgs_iters sweeps are spent.
+  auto exact_sweeps = [&](auto first) {
+    constexpr int kFirst = decltype(first)::value;
+    const int nfirst = pgs_iters < kExactFirst ? pgs_iters : kExactFirst;
+    for (int k = 0; k + 1 < nfirst; ++k) sweep(std::false_type{}, first, std::false_type{});
+    if (nfirst > 0) { moved = T(0); sweep(std::false_type{}, first, std::true_type{}); }
+    int sweeps = nfirst, solves = 0;
+    bool live = nfirst > 0 && moved > tol_v && sweeps < pgs_iters;
+    if constexpr (COUNT) {
+      unsigned nb = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if ((CMASK >> b) & 1u) nb += (kFirst >= 0 ? b >= kFirst : wave_act[b]) ? 1u : 0u;
+      wc.sweeps += (unsigned)nfirst; wc.body_sweeps += (unsigned)nfirst * nb; wc.live_lane_sweeps += (unsigned)nfirst * 64u;
+    }
+    // the loop is wave-uniform, what a lane does in it is its own business: a lane whose step was cut solves again
+    // while another takes its sweep
+    for (;;) {
+      if (__ballot(live) == 0ull) break;
+      const bool do_solve = live && solves < pgs_exact;
+      if constexpr (COUNT) {
+        const unsigned long long sv = __ballot(do_solve);
+        if (sv != 0ull) { wc.exact_solves += 1u; wc.lane_exact_solves += (unsigned)__popcll(sv); }
+      }
+      bool again = false;
+      OS2R_STAMP(8);
+      if (do_solve) {
+        again = exact_solve(first);
+        ++solves;
+        again = again && solves < pgs_exact;
+      }
+      OS2R_STAMP(18);   // the exact solves of phase 2 (its sweeps stay on stamp 8)
+      const bool do_sweep = live && !again;
+      if constexpr (COUNT) {
+        const unsigned long long wv = __ballot(do_sweep);
+        if (wv != 0ull) {
+          unsigned nb = 0;
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            if ((CMASK >> b) & 1u) nb += (kFirst >= 0 ? b >= kFirst : wave_act[b]) ? 1u : 0u;
+          wc.sweeps += 1u; wc.body_sweeps += nb; wc.live_lane_sweeps += (unsigned)__popcll(wv);
+        }
+      }
+      if (do_sweep) {
+        moved = T(0);
+        sweep(std::false_type{}, first, std::true_type{});
+        ++sweeps;
+        live = moved > tol_v && sweeps < pgs_iters;
+      }
+    }
+  };
   int first_act = NB;
   bool is_suffix = true;
 #pragma unroll
@@ -1256,7 +1511,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_STAMP(7);
 #pragma unroll
     for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
-    grouped_sweeps(std::false_type{}, first);
+    if constexpr (sizeof(T) == 8 && EXACT_ONLY) {
+      exact_sweeps(first);
+    } else if constexpr (sizeof(T) == 8) {
+      if (pgs_exact > 0) exact_sweeps(first);
+      else grouped_sweeps(std::false_type{}, first);
+    } else {
+      grouped_sweeps(std::false_type{}, first);
+    }
   };
   if (!fixed_box) {
 #pragma unroll
@@ -1267,6 +1529,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   }
   OS2R_STAMP(8);
   // back to joint velocities: v += Lc (y - y0)
+  if constexpr (kParkY0) {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) y0[i] = L(kY0Slot + i);
+  }
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     T acc_ = 0;

@@ -468,9 +468,10 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   WorkCounts wc;
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR, COUNT>(md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
-                                       STD_SWEEPS ? kStdPgsIters : A.pgs_iters, STD_SWEEPS ? kStdPgsNormalIters : A.pgs_normal_iters,
-                                       A.pgs_tol, tile, cand_lds, as_const(A.model), wc
+    substep<T, MD, CONTACT, DR, COUNT, STD_SWEEPS && StdSolver<T>::kExact>(
+                                       md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
+                                       STD_SWEEPS ? StdSolver<T>::kIters : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
+                                       A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc
 #ifdef OS2R_STAMPS
                                        , stamps, stamp_prev
 #endif
@@ -480,7 +481,8 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   if constexpr (COUNT) {
     if (A.counters && lane == 0) {
       const unsigned long long v[kWorkCounters] = {(unsigned long long)A.substeps, wc.scanned, wc.row_bodies, wc.body_sweeps,
-                                                    wc.sweeps, wc.lane_contacts, wc.live_lane_sweeps, wc.full_sincos};
+                                                    wc.sweeps, wc.lane_contacts, wc.live_lane_sweeps, wc.full_sincos,
+                                                    wc.exact_solves, wc.lane_exact_solves};
 #pragma unroll
       for (int k = 0; k < kWorkCounters; ++k) atomicAdd(A.counters + k, v[k]);
     }

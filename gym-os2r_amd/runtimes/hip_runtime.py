@@ -92,7 +92,8 @@ class HipRuntime:
                  real_time_factor: float = float(np.finfo(np.float32).max), *,
                  num_envs: int = 1, device=None, seed: int = 0, dtype: str = "f64",
                  contact: bool = True, max_episode_steps: int = 0, env_offset: int = 0,
-                 pgs_iters: int = 20, pgs_normal_iters: int = 3, auto_reset: bool = True,
+                 pgs_iters: Optional[int] = None, pgs_normal_iters: int = 3, pgs_exact: Optional[int] = None,
+                 pgs_tol: Optional[float] = None, auto_reset: bool = True,
                  physics_engine=None, world: Optional[str] = None, **kwargs):
         steps = physics_rate / agent_rate
         if steps != int(steps):
@@ -107,8 +108,12 @@ class HipRuntime:
         self.num_envs = int(num_envs)
         self._opts = dict(device=device, seed=int(seed), dtype=dtype, contact=bool(contact),
                           max_episode_steps=int(max_episode_steps), env_offset=int(env_offset),
-                          pgs_iters=int(pgs_iters), pgs_normal_iters=int(pgs_normal_iters),
-                          auto_reset=bool(auto_reset))
+                          # contact solver (abi.config_struct has the defaults: fp64 -- 3 + at most 12 sweeps with the exact
+                          # finish, 12 solves at most; `pgs_exact=0, pgs_iters=20` is the sweeps-only solver of rounds 1-2;
+                          # `pgs_tol` [J] is the stopping tolerance of the sweeps, 1e-24 in fp64 and 1e-13 in fp32)
+                          pgs_iters=None if pgs_iters is None else int(pgs_iters), pgs_normal_iters=int(pgs_normal_iters),
+                          pgs_exact=None if pgs_exact is None else int(pgs_exact),
+                          pgs_tol=None if pgs_tol is None else float(pgs_tol), auto_reset=bool(auto_reset))
         # set by the randomizer wrappers before the first reset (randomizers/*.py)
         self._reset_mode = abi.RESET_FIXED
         self._randomize_params = False
@@ -154,7 +159,8 @@ class HipRuntime:
                                     env_offset=o["env_offset"], seed=o["seed"],
                                     substeps=self.num_of_steps_per_run, dt=1.0 / self._physics_rate,
                                     contact=o["contact"], pgs_iters=o["pgs_iters"],
-                                    pgs_normal_iters=o["pgs_normal_iters"], auto_reset=o["auto_reset"])
+                                    pgs_normal_iters=o["pgs_normal_iters"], pgs_exact=o["pgs_exact"],
+                                    pgs_tol=o["pgs_tol"], auto_reset=o["auto_reset"])
             self._sim = HipSim(cfg, device=o["device"])
             self._bad_seen, self._bad_pending = 0, [False, False]     # a new handle counts from zero
         return self._sim

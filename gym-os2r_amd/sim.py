@@ -119,6 +119,7 @@ class HipSim:
         # a robot that is not compiled in gets its own kernels (gym_os2r_amd/jit.py; OS2R_JIT=0: generic ones)
         from . import jit
         self.specialised = jit.specialise(_lib.load(), cfg)
+        self._counters = None                         # count_work(True) allocates the work counters
         self._h = C.c_void_p()
         rc = self._lib.os2r_create(C.byref(cfg), C.byref(self._h))
         if rc != abi.OK:
@@ -181,16 +182,20 @@ class HipSim:
         return float(ms.value)
 
     WORK_COUNTERS = ("wave_iterations", "scanned_bodies", "row_bodies", "body_sweeps", "sweeps", "lane_contacts",
-                     "live_lane_sweeps", "full_sincos")
+                     "live_lane_sweeps", "full_sincos", "exact_solves", "lane_exact_solves")
 
     def count_work(self, on: bool = True):
         """Switch the counting variant of the step kernel on (include/os2r.h: os2r_set_work_counters) or off.
         While on, `work_counters()` returns what the launches since have added up."""
-        self._counters = torch.zeros(len(self.WORK_COUNTERS), dtype=torch.int64, device=self.device) if on else None
+        new = torch.zeros(len(self.WORK_COUNTERS), dtype=torch.int64, device=self.device) if on else None
+        # nothing may still be writing the old buffer, and the handle must stop pointing at it, before it is released
         torch.cuda.current_stream(self.device).synchronize()
-        self._check(self._lib.os2r_set_work_counters(self._h, _ptr(self._counters)), "os2r_set_work_counters")
+        self._check(self._lib.os2r_set_work_counters(self._h, _ptr(new)), "os2r_set_work_counters")
+        self._counters = new
 
     def work_counters(self, clear: bool = True) -> dict:
+        if getattr(self, "_counters", None) is None:
+            raise Os2rError("work counting is off: call count_work(True) first")
         torch.cuda.current_stream(self.device).synchronize()
         v = self._counters.cpu().tolist()
         if clear:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define OS2R_ABI_VERSION 2
+#define OS2R_ABI_VERSION 3
 
 #define OS2R_MAX_DOF 5      /* yaw, pitch, boom_connector, hip, knee                       */
 #define OS2R_MAX_CAND 192   /* ground-contact candidate points of one model                */
@@ -157,15 +157,24 @@ typedef struct Os2rConfig {
   int32_t substeps;        /* physics_rate/agent_rate = 10 (runtimes/gazebo_runtime.py:46)   */
   double dt;               /* 1/physics_rate = 1e-4 s                                        */
   int32_t contact;         /* 0: ground contact off (bring-up config C2), 1: on              */
-  int32_t pgs_iters;       /* projected Gauss-Seidel sweeps per substep over all rows        */
+  int32_t pgs_iters;       /* upper bound on the projected Gauss-Seidel sweeps per substep   */
+                           /*   over all rows (phase 2)                                      */
   int32_t pgs_normal_iters;/* preceding sweeps over normal + joint-friction rows that fix    */
                            /*   the tangential bounds (0: coupled pyramid)    */
   int32_t auto_reset;      /* SubprocVecEnv semantics (common/vec_env/subproc_vec_env.py:15) */
   double erp;              /* contact error-reduction parameter                              */
   double max_erv;          /* cap on the error-reduction velocity [m/s]                      */
   double contact_margin;   /* candidates closer than this to the ground join the contact [m] */
-  double pgs_tol;          /* an environment stops sweeping once a checked sweep (every 4th) moved */
-                           /*   no more energy than this [J]; 0: exact fixed points only          */
+  double pgs_tol;          /* an environment stops sweeping once a checked sweep moved no more     */
+                           /*   energy than this [J]; 0: exact fixed points only                   */
+  int32_t pgs_exact;       /* exact finish of the boxed LCP: an environment that   */
+                           /*   has not converged after the first 3 sweeps of phase 2 solves its    */
+                           /*   free rows exactly (a 5x5 system in the whitened velocities), with  */
+                           /*   active-set pivots, at most this many solves per substep; a checked */
+                           /*   sweep follows each unblocked solve.  0: sweeps only, checked every */
+                           /*   4th (the round-1/2 solver).  Ignored with pgs_normal_iters == 0;   */
+                           /*   needs dtype OS2R_F64.                                              */
+  int32_t reserved0_;
   Os2rModel model;
   Os2rTaskSpec task;
 } Os2rConfig;
@@ -271,10 +280,11 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
  * arithmetic, bit for bit -- whose waves add the work they did to it: [0] wave x physics iterations, [1] bodies whose
  * candidate scan ran, [2] bodies whose contact rows were set up, [3] phase-2 sweeps x bodies they covered,
  * [4] phase-2 sweeps executed, [5] (environment, body) contacts, [6] phase-2 sweeps x environments still live in
- * them, [7] wave x iterations that evaluated sin/cos in full.  Counting variants exist for the compiled-in robots
+ * them, [7] wave x iterations that evaluated sin/cos in full, [8] exact free-set solves executed by waves, [9] exact
+ * solves x environments that took part.  Counting variants exist for the compiled-in robots
  * with ground contact, the default sweep counts and a reference task layout (OS2R_ERR_INVALID otherwise).
  * NULL switches counting off.                                                                                   */
-#define OS2R_NUM_WORK_COUNTERS 8
+#define OS2R_NUM_WORK_COUNTERS 10
 int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
 
 const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */

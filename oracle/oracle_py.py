@@ -178,6 +178,16 @@ class OracleSim:
         """CONTACT_CENTROID (the specification, default) or CONTACT_PER_VERTEX (comparison model)."""
         lib().orc_set_contact_model(self._h, int(model))
 
+    def solver_counts(self):
+        """Diagnostics: (sweeps, solves), int8 [substeps, N] -- the phase-2 sweeps and exact solves of every physics
+        iteration of the last step.  The first call switches the recording on and returns None."""
+        n = int(self.cfg.substeps)
+        sw = np.zeros((n, self.N), dtype=np.int8)
+        so = np.zeros((n, self.N), dtype=np.int8)
+        if lib().orc_get_solver_counts(self._h, _p(sw), _p(so)):
+            return None
+        return sw, so
+
     def close(self):
         if self._h:
             lib().orc_destroy(self._h)

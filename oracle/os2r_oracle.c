@@ -634,7 +634,130 @@ static int block_update(int n, Row* rows, int r0, double* v, double* moved) {
 static int g_row_order = 0;
 void orc_set_experimental_row_order(int order) { g_row_order = order; }
 
-static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, double* v) {
+/* ---- exact finish of the fixed-box problem (cfg->pgs_exact) ----
+ * Gauss-Seidel identifies the active set of most problems within three sweeps and then crawls on the few whose rows
+ * are nearly collinear in the whitened metric (contraction 0.9 per sweep) or degenerate (a sticking foot plus sticking
+ * joints: eight rows in five dof).  An environment that has not converged after ORC_EXACT_FIRST sweeps therefore
+ * solves its FREE rows (strictly inside their box) exactly, all other rows held at their bounds:
+ *     whitened coordinates  Minv = Lc Lc^T,  y = Lc^-1 v,  g_r = Lc^T J_r   (so J_r v = g_r . y,  Minv J_r^T = Lc g_r)
+ *     minimum-norm change d of y with  g_r . (y + d) = t_r  for r in F:
+ *         (S + eps I) d = -sum_F g_r w_r,   S = sum_F g_r g_r^T (5 x 5, whatever |F| is),  w_r = g_r . y - t_r,
+ *         eps = ORC_EXACT_EPS * trace S,  ORC_EXACT_PROX proximal iterations (d_k from h + eps d_{k-1}) sharpen it;
+ *         the impulses of the free rows follow from the residuals:  mu_r = -(K w_r + g_r . sum_k d_k) / eps
+ *     (the regularisation keeps d in the range of the free rows, and 8 sticking rows in 5 dof are no special case).
+ * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
+ * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
+ * row and measures what it moved.  At most `exact` solves per physics iteration; the sweep cap `iters` still holds. */
+#define ORC_EXACT_FIRST 3
+#define ORC_EXACT_EPS 1e-6
+#define ORC_EXACT_PROX 3
+#define ORC_EXACT_SNAP 1e-12
+
+static void chol_lower(int n, const double* a, double* l) {   /* a = l l^T, row-major n x n */
+  for (int i = 0; i < n * n; ++i) l[i] = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double s = a[j * n + j];
+    for (int k = 0; k < j; ++k) s -= l[j * n + k] * l[j * n + k];
+    l[j * n + j] = sqrt(s);
+    for (int i = j + 1; i < n; ++i) {
+      double t = a[i * n + j];
+      for (int k = 0; k < j; ++k) t -= l[i * n + k] * l[j * n + k];
+      l[i * n + j] = t / l[j * n + j];
+    }
+  }
+}
+
+static void row_box(const Row* rows, const Row* R, int fixed_box, double* lo, double* hi) {
+  if (R->kind == 0) { *lo = 0.0; *hi = INFINITY; }
+  else if (R->kind == 1) { *hi = fixed_box ? R->bound : R->bound * rows[R->normal_row].lambda; *lo = -*hi; }
+  else { *hi = R->bound; *lo = -*hi; }
+}
+
+/* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
+static int exact_step(int n, Row* rows, int nr, const double* lc, double* v) {
+  double g[3 * OS2R_MAX_DOF + OS2R_MAX_DOF][OS2R_MAX_DOF], w[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+  int fr[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+  double S[OS2R_MAX_DOF][OS2R_MAX_DOF] = {{0}}, h[OS2R_MAX_DOF] = {0};
+  double tr = 0.0;
+  for (int r = 0; r < nr; ++r) {
+    const Row* R = &rows[r];
+    double lo, hi; row_box(rows, R, 1, &lo, &hi);
+    fr[r] = R->d > 0.0 && R->lambda > lo && R->lambda < hi;
+    if (!fr[r]) continue;
+    for (int k = 0; k < n; ++k) { double s = 0; for (int j = k; j < n; ++j) s += R->J[j] * lc[j * n + k]; g[r][k] = s; }
+    double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
+    w[r] = res;
+    for (int i = 0; i < n; ++i) { h[i] -= g[r][i] * res; for (int j = 0; j < n; ++j) S[i][j] += g[r][i] * g[r][j]; }
+  }
+  for (int i = 0; i < n; ++i) tr += S[i][i];
+  if (!(tr > 0.0)) return 0;                       /* no free row: nothing to solve */
+  const double eps = ORC_EXACT_EPS * tr;
+  /* L D L^T of S + eps I (symmetric positive definite), natural order */
+  double Lf[OS2R_MAX_DOF][OS2R_MAX_DOF] = {{0}}, D[OS2R_MAX_DOF];
+  for (int j = 0; j < n; ++j) {
+    double dj = S[j][j] + eps;
+    for (int k = 0; k < j; ++k) dj -= Lf[j][k] * Lf[j][k] * D[k];
+    D[j] = dj;
+    for (int i = j + 1; i < n; ++i) {
+      double t = S[i][j];
+      for (int k = 0; k < j; ++k) t -= Lf[i][k] * Lf[j][k] * D[k];
+      Lf[i][j] = t / dj;
+    }
+  }
+  double d[OS2R_MAX_DOF] = {0}, ds[OS2R_MAX_DOF] = {0};
+  for (int it = 0; it < ORC_EXACT_PROX; ++it) {
+    double z[OS2R_MAX_DOF];
+    for (int i = 0; i < n; ++i) z[i] = h[i] + (it > 0 ? eps * d[i] : 0.0);
+    for (int i = 0; i < n; ++i) for (int k = 0; k < i; ++k) z[i] -= Lf[i][k] * z[k];
+    for (int i = 0; i < n; ++i) z[i] /= D[i];
+    for (int i = n - 1; i >= 0; --i) for (int k = i + 1; k < n; ++k) z[i] -= Lf[k][i] * z[k];
+    for (int i = 0; i < n; ++i) { d[i] = z[i]; ds[i] += z[i]; }
+  }
+  /* impulses of the free rows; does the full step take one of them out of its box? */
+  double mu[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+  int cut = 0;
+  for (int r = 0; r < nr; ++r) {
+    if (!fr[r]) continue;
+    double s = ORC_EXACT_PROX * w[r];
+    for (int k = 0; k < n; ++k) s += g[r][k] * ds[k];
+    mu[r] = -s / eps;
+    double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+    const double full = rows[r].lambda + mu[r];
+    if (full < lo || full > hi) cut = 1;
+  }
+  /* if so, the largest feasible fraction of the step */
+  double alpha = 1.0;
+  if (cut)
+    for (int r = 0; r < nr; ++r) {
+      if (!fr[r] || mu[r] == 0.0) continue;
+      double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+      if (mu[r] > 0.0 && !isfinite(hi)) continue;
+      const double lim = ((mu[r] > 0.0 ? hi : lo) - rows[r].lambda) / mu[r];
+      if (lim < alpha) alpha = lim;
+    }
+  /* the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
+   * that the cut step has taken to its bound (the room left is below ORC_EXACT_SNAP of what it had) is set on it */
+  for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k <= i; ++k) s += lc[i * n + k] * d[k]; v[i] += alpha * s; }
+  for (int r = 0; r < nr; ++r) {
+    if (!fr[r]) continue;
+    double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+    const double l = rows[r].lambda;
+    double nl = l + alpha * mu[r];
+    if (cut) {
+      if (mu[r] > 0.0 && isfinite(hi) && hi - nl <= ORC_EXACT_SNAP * (hi - l)) nl = hi;
+      if (mu[r] < 0.0 && nl - lo <= ORC_EXACT_SNAP * (l - lo)) nl = lo;
+    }
+    if (nl < lo) nl = lo;
+    if (nl > hi) nl = hi;
+    rows[r].lambda = nl;
+  }
+  return cut;
+}
+
+/* diagnostics: phase-2 sweeps and exact solves of the calling thread's last solve (orc_get_solver_counts) */
+static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
+
+static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, int exact, const double* minv, double* v) {
   int order[ORC_MAX_ROWS];
   for (int r = 0; r < nr; ++r) order[r] = r;
   if (g_row_order != 0)
@@ -644,11 +767,24 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         order[r] = y_first ? r + 2 : r + 1; order[r + 1] = y_first ? r + 1 : r + 2; order[r + 2] = r;
         r += 2;
       }
+  if (normal_iters <= 0) exact = 0;               /* the coupled pyramid has no fixed box to pivot on */
+  double lc[OS2R_MAX_DOF * OS2R_MAX_DOF];
+  if (exact > 0) chol_lower(n, minv, lc);
   for (int phase = 0; phase < 2; ++phase) {
     const int sweeps = phase == 0 ? normal_iters : iters;
     if (phase == 1 && normal_iters > 0)
       for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
+    int solves = 0;
+    if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; }
     for (int it = 0; it < sweeps; ++it) {
+      /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
+       * the step short) precede every sweep until the budget `exact` is spent */
+      if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST && solves < exact) {
+        int blocked = 1;
+        while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v); ++solves; }
+        tl_last_solves = solves;
+      }
+      if (phase == 1) tl_last_sweeps = it + 1;
       double moved = 0.0;
       for (int ri = 0; ri < nr; ++ri) {
         const int r = (phase == 1 && !g_block_solve) ? order[ri] : ri;
@@ -659,9 +795,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         if (phase == 0 && R->kind == 1) continue;
         double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
         double lam = R->lambda - res / R->d, lo, hi;
-        if (R->kind == 0) { lo = 0.0; hi = INFINITY; }
-        else if (R->kind == 1) { hi = normal_iters > 0 ? R->bound : R->bound * rows[R->normal_row].lambda; lo = -hi; }
-        else { hi = R->bound; lo = -hi; }
+        row_box(rows, R, normal_iters > 0, &lo, &hi);
         if (lam < lo) lam = lo;
         if (lam > hi) lam = hi;
         double dl = lam - R->lambda;
@@ -669,7 +803,9 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         moved += fabs(res) * fabs(dl);
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
-      if (phase == 1 && (it + 1) % ORC_PGS_GROUP == 0 && it + 1 < sweeps && moved <= tol) break;
+      if (phase == 1 && it + 1 < sweeps && moved <= tol) {
+        if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST : (it + 1) % ORC_PGS_GROUP == 0) break;
+      }
     }
   }
 }
@@ -680,11 +816,11 @@ static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvPar
   if (contact_model == ORC_CONTACT_CENTROID) {
     Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
     const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
-    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, v);
+    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, cfg->pgs_exact, minv, v);
   } else {
     Row* rows = (Row*)malloc(sizeof(Row) * ORC_MAX_ROWS);
     const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
-    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, v);
+    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, 0, minv, v);
     free(rows);
   }
   for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += cfg->dt * v[i]; }
@@ -743,7 +879,7 @@ int orc_contact_problem(const Os2rConfig* cfg, int contact_model, const double* 
     for (int i = 0; i < 3; ++i) point[3 * r + i] = rows[r].point[i];
   }
   const int coupled = contact_model != ORC_CONTACT_CENTROID || cfg->pgs_normal_iters == 0;
-  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, v);
+  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, coupled ? 0 : cfg->pgs_exact, minv, v);
   for (int r = 0; r < nr; ++r) {
     lambda[r] = rows[r].lambda;
     if (rows[r].kind == 0) box[r] = INFINITY;
@@ -769,6 +905,7 @@ struct OrcSim {
   uint64_t step_count;
   int nthreads;
   int contact_model;   /* ORC_CONTACT_*: the specification unless a test asks for the comparison model */
+  int8_t* solver_counts; /* diagnostics, [2][substeps][N]: phase-2 sweeps / exact solves of every physics iteration of the last step */
 };
 
 static void load_params(const OrcSim* s, int64_t e, EnvParams* ep) {
@@ -870,11 +1007,19 @@ int orc_create(const Os2rConfig* cfg, OrcSim** out) {
 void orc_destroy(OrcSim* s) {
   if (!s) return;
   free(s->q); free(s->qd); free(s->hist); free(s->mass_scale); free(s->damping); free(s->friction);
-  free(s->mu); free(s->gravity); free(s->steps); free(s->episode); free(s->pose); free(s);
+  free(s->mu); free(s->gravity); free(s->steps); free(s->episode); free(s->pose); free(s->solver_counts); free(s);
 }
 
 void orc_set_threads(OrcSim* s, int n) { s->nthreads = n < 1 ? 1 : n; }
 void orc_set_contact_model(OrcSim* s, int model) { s->contact_model = model; }
+/* diagnostics: record, from now on, the phase-2 sweeps and exact solves of every physics iteration of a step */
+int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves) {
+  const size_t n = (size_t)s->cfg.substeps * s->N;
+  if (!s->solver_counts) { s->solver_counts = (int8_t*)calloc(2 * n, 1); return 1; }   /* first call switches recording on */
+  if (sweeps) memcpy(sweeps, s->solver_counts, n);
+  if (solves) memcpy(solves, s->solver_counts + n, n);
+  return 0;
+}
 
 static void observe_env(const OrcSim* s, int64_t e, double* obs) {
   const int n = s->cfg.model.nq; const int64_t N = s->N;
@@ -912,7 +1057,13 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
     double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
     EnvParams ep; load_params(s, e, &ep);
     for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
-    for (int k = 0; k < cfg->substeps; ++k) substep_model(cfg, s->contact_model, &ep, q, qd, tau);      /* gazebo_runtime.py:70-77 */
+    for (int k = 0; k < cfg->substeps; ++k) {                                                          /* gazebo_runtime.py:70-77 */
+      substep_model(cfg, s->contact_model, &ep, q, qd, tau);
+      if (s->solver_counts) {
+        s->solver_counts[(size_t)k * s->N + e] = (int8_t)(tl_last_sweeps > 127 ? 127 : tl_last_sweeps);
+        s->solver_counts[((size_t)cfg->substeps + k) * s->N + e] = (int8_t)(tl_last_solves > 127 ? 127 : tl_last_solves);
+      }
+    }
     int bad = 0;
     for (int i = 0; i < n; ++i) { if (!isfinite(q[i]) || !isfinite(qd[i])) bad = 1; s->q[i * N + e] = q[i]; s->qd[i * N + e] = qd[i]; }
     /* action_history.appendleft (monopod.py:232-235) */

@@ -48,6 +48,7 @@ int orc_create(const Os2rConfig* cfg, OrcSim** out);
 void orc_destroy(OrcSim* s);
 void orc_set_threads(OrcSim* s, int n);
 void orc_set_contact_model(OrcSim* s, int model);
+int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves);   /* diagnostics: [substeps][N] each, of the last step; the first call switches recording on */
 void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
 void orc_set_experimental_row_order(int order);
 int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);

@@ -103,3 +103,85 @@ def pgs_two_phase(p, normal_iters=3, iters=20, tol=1e-24, group=4):
                 if (it + 1) % group == 0 and it + 1 < iters and moved <= tol:
                     break
     return v, lam, box, ran
+
+
+def pgs_exact_finish(p, normal_iters=3, iters=12, tol=1e-24, exact=12, first=3, eps_rel=1e-6, prox=3, snap=1e-12):
+    """The specification's solver with the exact finish, restated on the
+    exported rows: phase 1 as in pgs_two_phase; phase 2 = `first` sweeps, then -- while the last sweep moved more than
+    `tol` -- exact solves of the free rows (repeated while a bound cuts the step short, `exact` at most) each followed
+    by one sweep; `iters` bounds the sweeps.  -> (v, lam, box, sweeps of phase 2, exact solves)"""
+    J, minv, t, kind, nrow = p["J"], p["minv"], p["target"], p["kind"], p["normal_row"]
+    nr, n = J.shape
+    Lc = np.linalg.cholesky(minv)
+    G = J @ Lc                         # rows in the whitened coordinates y = Lc^-1 v
+    d = np.einsum("rk,rk->r", G, G)
+    y = np.linalg.solve(Lc, p["vstar"])
+    lam = np.zeros(nr)
+    box = p["bound"].copy()
+
+    def sweep(rows, lo, hi):
+        moved = 0.0
+        for r in rows:
+            if not d[r] > 0:
+                continue
+            res = G[r] @ y - t[r]
+            new = min(max(lam[r] - res / d[r], lo[r]), hi[r])
+            dl = new - lam[r]
+            lam[r] = new
+            moved += abs(res) * abs(dl)
+            y[:] += G[r] * dl
+        return moved
+
+    lo = np.where(kind == 0, 0.0, -box)
+    hi = np.where(kind == 0, np.inf, box)
+    for _ in range(normal_iters):
+        sweep([r for r in range(nr) if kind[r] != 1], lo, hi)
+    for r in range(nr):
+        if kind[r] == 1:
+            box[r] = p["bound"][r] * lam[nrow[r]]
+    lo = np.where(kind == 0, 0.0, -box)
+    hi = np.where(kind == 0, np.inf, box)
+    ran = solves = 0
+    for it in range(iters):
+        if it >= first and solves < exact:
+            blocked = True
+            while blocked and solves < exact:
+                solves += 1
+                F = (d > 0) & (lam > lo) & (lam < hi)
+                S = G[F].T @ G[F]
+                tr = np.trace(S)
+                if not tr > 0:
+                    blocked = False
+                    break
+                eps = eps_rel * tr
+                w = G[F] @ y - t[F]
+                h = -G[F].T @ w
+                A = S + eps * np.eye(n)
+                dk = np.zeros(n)
+                ds = np.zeros(n)
+                for k in range(prox):
+                    dk = np.linalg.solve(A, h + eps * dk)
+                    ds += dk
+                mu = -(prox * w + G[F] @ ds) / eps
+                full = lam[F] + mu
+                blocked = bool(((full < lo[F]) | (full > hi[F])).any())      # the full step leaves a box: cut it
+                alpha = 1.0
+                if blocked:
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        lim = np.where(mu > 0, (hi[F] - lam[F]) / mu, np.where(mu < 0, (lo[F] - lam[F]) / mu, np.inf))
+                    alpha = min(1.0, lim.min())
+                y += alpha * dk
+                idx = np.nonzero(F)[0]
+                for j, m in zip(idx, mu):
+                    nl = lam[j] + alpha * m
+                    if blocked:                      # a row the cut step has taken to its bound is set on it
+                        if m > 0 and np.isfinite(hi[j]) and hi[j] - nl <= snap * (hi[j] - lam[j]):
+                            nl = hi[j]
+                        if m < 0 and nl - lo[j] <= snap * (lam[j] - lo[j]):
+                            nl = lo[j]
+                    lam[j] = min(max(nl, lo[j]), hi[j])
+        moved = sweep(range(nr), lo, hi)
+        ran += 1
+        if it + 1 < iters and it + 1 >= first and moved <= tol:
+            break
+    return Lc @ y, lam, box, ran, solves

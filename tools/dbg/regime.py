@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import bench
 from gym_os2r_amd.sim import HipSim
 for wl in ("V1", "C4"):
-    ns = argparse.Namespace(workload=wl, envs_per_gpu=65536, dtype="f64", seed=42, pgs_iters=20, pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
+    ns = argparse.Namespace(workload=wl, envs_per_gpu=65536, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
     cfg, _, _ = bench.build_config(ns, 0, 1)
     sim = HipSim(cfg, device="cuda:0")
     out = []

@@ -19,14 +19,16 @@ import bench
 PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y)", "contact: forward kinematics",
           "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "prologue (once per env-step)", "epilogue: state stores (once per env-step)",
           "  dyn: body velocities", "  dyn: inward body 4", "  dyn: inward body 3", "  dyn: inward body 2", "  dyn: inward body 1",
-          "  dyn: inward body 0", "-", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)"]
+          "  dyn: inward body 0", "PGS phase 2: exact solves", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)"]
 NS = 26   # kStamps in os2r_device.hpp
 
 
 def main():
     class A:  # bench.build_config arguments
         workload = sys.argv[1] if len(sys.argv) > 1 else "C4"
-        envs_per_gpu = int(os.environ.get("OS2R_ENVS", "65536")); dtype = "f64"; seed = 42; pgs_iters = 20; pgs_normal_iters = 3
+        envs_per_gpu = int(os.environ.get("OS2R_ENVS", "65536")); dtype = "f64"; seed = 42; pgs_normal_iters = 3
+        pgs_iters = int(os.environ["OS2R_PGS_ITERS"]) if "OS2R_PGS_ITERS" in os.environ else None
+        pgs_exact = int(os.environ["OS2R_PGS_EXACT"]) if "OS2R_PGS_EXACT" in os.environ else None
         pgs_tol = float(os.environ["OS2R_PGS_TOL"]) if "OS2R_PGS_TOL" in os.environ else None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
     from gym_os2r_amd.sim import HipSim
