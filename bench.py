@@ -25,6 +25,7 @@ Rank 0 prints ONE JSON line: the contract keys plus
   cpu_baseline  the CPU oracle (scalar fp64 port) timed on this box's host cores, N=1 only
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -51,7 +52,8 @@ WORKLOADS = {
 }
 
 
-def build_config(args, rank, world):
+def build_config(args, rank, world, split=0, splits=1):
+    """Config of rank `rank` of `world` (contiguous shard `rank * envs_per_gpu ...`), or of shard `split` of `splits` of it."""
     import gym_os2r_amd as g
     from gym_os2r_amd import abi, rewards
     from gym_os2r_amd.tasks.monopod import MonopodTask
@@ -66,9 +68,14 @@ def build_config(args, rank, world):
     spec = task.kernel_spec(model, reset_mode=abi.RESET_RANDOM if dr else abi.RESET_FIXED,
                             randomize_params=dr, max_episode_steps=100_000)
     n = args.envs_per_gpu
-    cfg = abi.config_struct(model, spec, num_envs=n, env_offset=rank * n, seed=args.seed,
+    base = rank * n
+    if splits > 1:
+        from gym_os2r_amd.distributed import shard_range
+        off, n = shard_range(args.envs_per_gpu, split, splits)
+        base += off
+    cfg = abi.config_struct(model, spec, num_envs=n, env_offset=base, seed=args.seed,
                             dtype=abi.F64 if args.dtype == "f64" else abi.F32, contact=contact,
-                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters, pgs_tol=args.pgs_tol, pgs_exact=args.pgs_exact)
+                            pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters, pgs_tol=args.pgs_tol, pgs_exact=getattr(args, 'pgs_exact', None))
     return cfg, model, spec
 
 
@@ -85,12 +92,27 @@ def algorithmic_bytes_per_env_step(cfg, esz):
     return reads + writes
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, cut down to the cgroup's CPU quota (a GPU box hands a
+    container a share of the host -- 16 cores per GPU on this pool -- while os.cpu_count() reports the whole machine;
+    64 threads on such a share is what made the round-2 baseline scale 9x on '64 cores')."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, cfg):
     """The CPU oracle (same algorithm, scalar fp64 C port) on the host cores: reported baseline."""
     import copy
     from oracle import oracle_py
     oracle_py.build()
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(host_cores(), 64)
     cfg2 = copy.copy(cfg)
     cfg2.num_envs = args.cpu_envs
     orc = oracle_py.OracleSim(cfg2, threads=cores)
@@ -116,7 +138,8 @@ def cpu_baseline(args, cfg):
     dt1 = time.perf_counter() - t1
     one.close()
     return {"value": steps * args.cpu_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} env-steps x {args.cpu_envs} envs of the same workload, OpenMP over envs, {dt:.1f} s",
+            "reference_runtime": "unavailable (gym-ignition / ScenarIO / Ignition Gazebo / DART are not installed here; SURVEY 8d item 2)",
+            "sample": f"{steps} env-steps x {args.cpu_envs} envs of the same workload, OpenMP over envs ({cores} threads = the cores this container may use; os.cpu_count() = {os.cpu_count()}), {dt:.1f} s",
             "single_core": {"value": steps1 * 128 / dt1, "sample": f"{steps1} env-steps x 128 envs, {dt1:.1f} s"}}
 
 
@@ -201,6 +224,10 @@ def main():
                     help="process-group backend for the barrier / max-time reduction (nccl = RCCL; gloo lets several "
                          "ranks share one GPU when rehearsing the multi-rank path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--splits", type=int, default=1,
+                    help="cut this rank's batch into that many contiguous shards, one handle and one stream each, advancing "
+                         "independently (a shard waits for its own slowest wave only; DESIGN.md 7).  Results per environment "
+                         "are those of the single batch, bit for bit")
     ap.add_argument("--gather-obs", action="store_true",
                     help="also gather obs / reward / done of every step to rank 0 (the optional RCCL collective of "
                          "SURVEY 8e; off the step path, so off by default): one launch + one gather per step")
@@ -226,6 +253,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the stepper has no CPU fallback")
     if args.share_gpu:
         local_rank = 0
+    if torch.cuda.device_count() < local_rank + 1:
+        raise SystemExit(f"rank {rank} (LOCAL_RANK {local_rank}) has no GPU: {torch.cuda.device_count()} device(s) visible; "
+                         "one process per GPU is expected (or --share-gpu for a rehearsal on one)")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("OS2R_BENCH_FORCE_DIST") == "1"   # the latter: rehearse RCCL init on one GPU
     if use_dist:
@@ -235,20 +265,37 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if use_dist and dist.get_world_size() != world:
+        raise SystemExit(f"WORLD_SIZE={world} but the process group has {dist.get_world_size()} ranks")
+    S = max(1, args.splits)
+    if S > 1 and args.gather_obs:
+        raise SystemExit("--splits and --gather-obs are separate experiments")
     cfg, model, spec = build_config(args, rank, world)
-    sim = HipSim(cfg, device=f"cuda:{local_rank}")
     esz = 8 if args.dtype == "f64" else 4
+    if S == 1:
+        sims, streams = [HipSim(cfg, device=f"cuda:{local_rank}")], [None]
+    else:
+        # shards of this rank's batch: a handle and a stream each, advancing independently
+        sims = [HipSim(build_config(args, rank, world, i, S)[0], device=f"cuda:{local_rank}") for i in range(S)]
+        streams = [torch.cuda.Stream(device=sims[0].device) for _ in range(S)]
+    sim = sims[0]
+
+    def on(i):
+        return torch.cuda.stream(streams[i]) if streams[i] is not None else contextlib.nullcontext()
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.preroll > 0:
-        sim.bench_steps(args.preroll)
-    if args.warmup > 0:
-        sim.bench_steps(args.warmup)
-    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64"
+    for i in range(S):
+        with on(i):
+            if args.preroll > 0:
+                sims[i].bench_enqueue(args.preroll)
+            if args.warmup > 0:
+                sims[i].bench_enqueue(args.warmup)
+    torch.cuda.synchronize()
+    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64" and S == 1
     for _ in range(3 if use_dist else 0):
         barrier()                                     # communicator set-up and first-use costs of the barrier itself stay outside
     ck = sim.checkpoint() if count else None          # for the counting replay of the timed window
@@ -257,26 +304,62 @@ def main():
     # up to 6 % slow (measured: 145.6 against 137.9 us per launch over 20 steps behind an RCCL barrier).  So a few more
     # untimed steps are in flight from here until the synchronize that ends the opening bracket.
     busy_steps = 40
-    keep = [torch.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device), torch.empty(args.envs_per_gpu, dtype=sim.dtype, device=sim.device),
-            torch.empty(args.envs_per_gpu, dtype=torch.uint8, device=sim.device), torch.empty(args.envs_per_gpu, sim.D, dtype=sim.dtype, device=sim.device)]
-    for _ in range(busy_steps):
-        sim.step_into(None, keep[0], keep[1], keep[2], keep[3])
+    for i in range(S):
+        with on(i):
+            sims[i].bench_enqueue(busy_steps)
     barrier()
     t0 = time.perf_counter()
-    if not args.gather_obs:
+    if S > 1:
+        # every shard's K launches go to its own stream (enqueue only: the host does not wait in between); the
+        # shard's launches run back to back there, so its events give its average launch duration
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
+        chunk = 50                                    # interleave the enqueueing so that no stream starts far behind
+        for k0 in range(0, args.steps, chunk):
+            for i in range(S):
+                with on(i):
+                    if k0 == 0:
+                        evs[i][0].record()
+                    sims[i].bench_enqueue(min(chunk, args.steps - k0))
+                    if k0 + chunk >= args.steps:
+                        evs[i][1].record()
+        torch.cuda.synchronize()
+        kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / S   # mean over the shards of (K launches of that shard)
+    elif not args.gather_obs:
         kernel_ms = sim.bench_steps(args.steps)       # K launches, HIP events on the launch stream
     else:
+        # The optional gather of SURVEY 8e / f-4: observations, rewards and done flags of every step travel to rank 0.
+        # Double-buffered and on a side stream: the gather of step k runs behind the launch of step k + 1 (5.9 MB per
+        # rank and step at 65 536 envs: ~40 us on one xGMI link against a ~140 us step), the host waits for nothing
+        # inside the loop, and a buffer is reused only after the gather that read it has finished (an event per buffer).
         from gym_os2r_amd.distributed import gather_to_rank0
-        host = use_dist and args.backend == "gloo"    # gloo gathers host tensors
+        host = use_dist and args.backend == "gloo"    # gloo gathers host tensors: that rehearsal path stays synchronous
+        n, D = args.envs_per_gpu, sim.D
+        bufs = [[torch.empty(n, D, dtype=sim.dtype, device=sim.device), torch.empty(n, dtype=sim.dtype, device=sim.device),
+                 torch.empty(n, dtype=torch.uint8, device=sim.device)] for _ in range(2)]
+        free = [None, None]                           # event: the gather that read buffer b has finished
+        side = torch.cuda.Stream(device=sim.device)
+        main = torch.cuda.current_stream(sim.device)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        kernel_ms = 0.0
-        for _ in range(args.steps):
-            ev0.record()
-            obs, rew, done, _ = sim.step(None, want_terminal=False)
-            ev1.record()
-            gathered = [gather_to_rank0(t.cpu() if host else t, args.envs_per_gpu * world) for t in (obs, rew, done)]
-            ev1.synchronize()
-            kernel_ms += ev0.elapsed_time(ev1)
+        ev0.record()
+        gathered = None
+        for k in range(args.steps):
+            b = k & 1
+            if free[b] is not None:
+                main.wait_event(free[b])
+            sim.step_into(None, bufs[b][0], bufs[b][1], bufs[b][2])
+            stepped = torch.cuda.Event()
+            stepped.record(main)
+            if host:
+                gathered = [gather_to_rank0(t.cpu(), n * world) for t in bufs[b]]
+            else:
+                side.wait_event(stepped)
+                with torch.cuda.stream(side):
+                    gathered = [gather_to_rank0(t, n * world) for t in bufs[b]]
+                    free[b] = torch.cuda.Event()
+                    free[b].record(side)
+        ev1.record()
+        torch.cuda.synchronize()
+        kernel_ms = ev0.elapsed_time(ev1)             # launches + whatever of the gathers was not hidden behind them
     # closing bracket: this rank's K steps are over when its device has drained; the clock is read there, then the
     # ranks meet at the barrier, and the MAX over ranks of the elapsed times below is when the slowest rank was done.
     # (Reading the clock behind the barrier would add the collective's own latency -- 150-400 us under RCCL, 5-10 % of
@@ -311,7 +394,9 @@ def main():
                        "pgs_tol": float(cfg.pgs_tol), "pgs_exact": int(cfg.pgs_exact), "preroll_steps": args.preroll,
                        "contact": bool(cfg.contact), "domain_randomisation": WORKLOADS[args.workload][3],
                        "actions": "U(-1,1) Philox on device",
-                       "sharding": f"envs x{world}, " + ("obs/reward/done gathered to rank 0 every step" if args.gather_obs else "no step-path collective")},
+                       "sharding": f"envs x{world}, " + ("obs/reward/done gathered to rank 0 every step (side stream, double-buffered)" if args.gather_obs else "no step-path collective"),
+                       "n_ranks_seen": dist.get_world_size() if use_dist else 1,
+                       "splits": S},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
@@ -319,7 +404,9 @@ def main():
                          "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " + str(traffic.get("source")) + "; not measured by this run)",
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "kernel_ms_per_launch": per_launch_s * 1e3,
-                         "note": "ALU-bound path: see roofline_valu"},
+                         "concurrent_launches": S,
+                         "note": "ALU-bound path: see roofline_valu" + ("" if S == 1 else f"; {S} shards on {S} streams: a step of the batch is {S} concurrent launches of "
+                                                                          "1/S of the bytes each, kernel_ms_per_launch is the mean launch duration of a shard and `achieved` the rate of all of them together")},
         }
         peak = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
         cf = counted_flops(sim, ck, args.steps, WORKLOADS[args.workload][3], args.workload, skip=busy_steps) if count else None
@@ -339,7 +426,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)
-    sim.close()
+    for s_ in sims:
+        s_.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -584,14 +584,15 @@ int os2r_set_step_count(Os2rSim* sim, uint64_t value) {
 }
 
 int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) {
-  if (!sim || nsteps < 1 || !elapsed_ms) return OS2R_ERR_INVALID;
+  if (!sim || nsteps < 1) return OS2R_ERR_INVALID;
   DeviceGuard guard(sim->cfg.device);
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(sim, hipEventRecord(sim->ev0, st));
+  if (elapsed_ms) HIP_TRY(sim, hipEventRecord(sim->ev0, st));
   for (int k = 0; k < nsteps; ++k) {
     int rc = os2r_step(sim, nullptr, sim->b_obs, sim->b_rew, sim->b_done, sim->b_term, stream);
     if (rc) return rc;
   }
+  if (!elapsed_ms) return OS2R_OK;   // enqueue only: several handles on several streams are timed by their caller
   HIP_TRY(sim, hipEventRecord(sim->ev1, st));
   HIP_TRY(sim, hipEventSynchronize(sim->ev1));
   HIP_TRY(sim, hipEventElapsedTime(elapsed_ms, sim->ev0, sim->ev1));

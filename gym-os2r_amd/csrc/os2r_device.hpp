@@ -1141,7 +1141,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   for (int j = 0; j < NQ; ++j) lf[j] = 0;
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
-    fb[j] = fb[j] * dt;
+    fb[j] = opaque(fb[j] * dt);
     idj[j] = fb[j] > T(0) ? idj[j] : T(0);
   }
 
@@ -1327,7 +1327,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     T tr = T(0);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) tr += S[tri(i, i)];
-    const T eps = tr > T(0) ? T(kExactEps) * tr : T(1);   // no free row: S = 0 and h = 0, the step is zero
+    // (values that are products and feed sums below are made opaque: left to the compiler, `a + b * c` is fused or not
+    // depending on the instantiation -- the specialised and the general form of a wave -- and on the branch taken,
+    // and a lane's result would depend on its company)
+    const T eps = opaque(tr > T(0) ? T(kExactEps) * tr : T(1));   // no free row: S = 0 and h = 0, the step is zero
     // S + eps I = Lf D Lf^T, natural order (symmetric positive definite: no pivoting).  Lf overwrites S (strict lower
     // part), Di holds the reciprocal pivots.
     T Di[NQ];
@@ -1348,7 +1351,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         if (k < j) {
-          const T ljk = u[k] * Di[k];
+          const T ljk = opaque(u[k] * Di[k]);
           dj = fma_t(-ljk, u[k], dj);
           S[tri(j, k)] = ljk;
         }
@@ -1368,7 +1371,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         for (int k = 0; k < NQ; ++k)
           if (k < i) z[i] = fma_t(-S[tri(i, k)], z[k], z[i]);
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) z[i] *= Di[i];
+      for (int i = 0; i < NQ; ++i) z[i] = opaque(z[i] * Di[i]);
 #pragma unroll
       for (int i = NQ - 1; i >= 0; --i)
 #pragma unroll
@@ -1400,7 +1403,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
         if (k <= nz) r = fma_t(g[k], ds[k], r);
-      const T m = r * f;
+      const T m = opaque(r * f);
       mu_put(slot, m);
       const T full = l + m;
       cut = cut | (full < lo) | (upper ? (full > hi) : false);
@@ -1415,7 +1418,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         const bool up = m > T(0);
         const bool bounded = (m < T(0)) | (upper ? up : false);
         const T room = (up ? hi : lo) - l;
-        const T lim = room * rcp_t(bounded ? m : T(1));   // same sign as m, so lim >= 0
+        const T lim = opaque(room * rcp_t(bounded ? m : T(1)));   // same sign as m, so lim >= 0
         a = (bounded & (lim < a)) ? lim : a;
       });
       alpha = cut ? a : T(1);
@@ -1510,7 +1513,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int it = 0; it < pgs_normal_iters; ++it) normal_sweep(first);
     OS2R_STAMP(7);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) limfix[b] = mub[b] * ln[b];
+    for (int b = 0; b < NB; ++b) limfix[b] = opaque(mub[b] * ln[b]);   // (a plain value: the exact finish subtracts from it)
     if constexpr (sizeof(T) == 8 && EXACT_ONLY) {
       exact_sweeps(first);
     } else if constexpr (sizeof(T) == 8) {

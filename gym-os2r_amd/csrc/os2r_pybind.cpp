@@ -49,6 +49,10 @@ PYBIND11_MODULE(_os2r_py, m) {
     { py::gil_scoped_release rel; rc = os2r_bench_steps(H(h), n, P(st), &ms); }
     return py::make_tuple(rc, ms);
   });
+  m.def("bench_enqueue", [](addr h, int n, addr st) {
+    py::gil_scoped_release rel;
+    return os2r_bench_steps(H(h), n, P(st), nullptr);
+  });
   m.def("set_work_counters", [](addr h, addr buf) { return os2r_set_work_counters(H(h), (uint64_t*)P(buf)); });
   m.def("model_is_compiled_in", [](addr model) { return os2r_model_is_compiled_in((const Os2rModel*)P(model)); });
   m.def("register_model_kernels", [](addr model, int dtype, int device, const std::string& path) {

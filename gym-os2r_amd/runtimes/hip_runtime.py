@@ -180,6 +180,10 @@ class HipRuntime:
         """actions [N, 2] in [-1, 1] -> (obs [N, D], reward [N], done [N] bool, BatchedInfo)."""
         import torch
         sim = self.sim
+        # DLPack at the boundary: a device array of another framework (anything with `__dlpack__`, or a DLPack
+        # capsule) is taken over without a copy; what comes back are torch tensors, which export `__dlpack__`
+        if not isinstance(actions, (torch.Tensor, np.ndarray, list, tuple)) and (hasattr(actions, "__dlpack__") or type(actions).__name__ == "PyCapsule"):
+            actions = torch.from_dlpack(actions)
         # The action space is enforced (gazebo_runtime.py:67-68 warns; the task asserts).  Host actions
         # are checked on the host before the upload.  Device actions are checked by the kernel and the
         # verdict is read two calls later (or in reset()/close()): reading it earlier would make the

@@ -84,6 +84,8 @@ class _PybindLib:
         return self.m.set_step_count(self._a(h), int(getattr(v, "value", v)))
 
     def os2r_bench_steps(self, h, n, st, ms_ref):
+        if ms_ref is None:
+            return self.m.bench_enqueue(self._a(h), int(n), self._a(st))
         rc, ms = self.m.bench_steps(self._a(h), int(n), self._a(st))
         ms_ref._obj.value = ms
         return rc
@@ -137,6 +139,10 @@ class HipSim:
         return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
 
     def _in(self, t, shape, dtype=None):
+        # anything that speaks DLPack (`__dlpack__`: another framework's device array, a capsule) is taken over without a
+        # copy when it already lives on this device in the handle's dtype; torch tensors and host arrays as before
+        if not isinstance(t, torch.Tensor) and (hasattr(t, "__dlpack__") or type(t).__name__ == "PyCapsule") and not hasattr(t, "__array_interface__"):
+            t = torch.from_dlpack(t)
         t = torch.as_tensor(t, device=self.device).to(dtype or self.dtype).contiguous()
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
@@ -180,6 +186,11 @@ class HipSim:
         ms = C.c_float()
         self._check(self._lib.os2r_bench_steps(self._h, int(nsteps), self._stream(), C.byref(ms)), "os2r_bench_steps")
         return float(ms.value)
+
+    def bench_enqueue(self, nsteps: int):
+        """Enqueue nsteps random-action steps on the current stream and return at once (no events, no wait): for
+        callers that drive several handles on several streams -- shards of one batch advancing independently."""
+        self._check(self._lib.os2r_bench_steps(self._h, int(nsteps), self._stream(), None), "os2r_bench_steps")
 
     WORK_COUNTERS = ("wave_iterations", "scanned_bodies", "row_bodies", "body_sweeps", "sweeps", "lane_contacts",
                      "live_lane_sweeps", "full_sincos", "exact_solves", "lane_exact_solves")

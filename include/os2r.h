@@ -272,7 +272,9 @@ int os2r_set_step_count(Os2rSim* sim, uint64_t value);
  * random actions on the given stream, bracketed by HIP events recorded on that
  * stream; returns the elapsed GPU time in milliseconds. Every output of os2r_step
  * (observation, reward, done, terminal observation) goes to internal scratch
- * buffers: the timed launch is the one a gym-level env.step makes.               */
+ * buffers: the timed launch is the one a gym-level env.step makes.
+ * elapsed_ms == NULL: the launches are only enqueued (no events, no synchronisation) -- for a caller that drives
+ * several handles on several streams (shards of one batch that advance independently) and times them itself.  */
 int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
 
 /* Work counters (measurement support, bench.py's roofline): while a buffer of OS2R_NUM_WORK_COUNTERS uint64 (device

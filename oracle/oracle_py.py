@@ -251,6 +251,16 @@ class OracleSim:
         lib().orc_get_episode_info(self._h, _p(steps), _p(epi), _p(pose))
         return steps, epi, pose
 
+    def set_episode_info(self, steps=None, episode=None, pose=None):
+        a = [None if steps is None else np.ascontiguousarray(steps, dtype=np.int32),
+             None if episode is None else np.ascontiguousarray(episode, dtype=np.uint32),
+             None if pose is None else np.ascontiguousarray(pose, dtype=np.uint8)]
+        assert all(x is None or x.shape == (self.N,) for x in a)
+        lib().orc_set_episode_info(self._h, _p(a[0]), _p(a[1]), _p(a[2]))
+
+    def set_step_count(self, v):
+        self.step_count = v
+
     @property
     def step_count(self):
         return int(lib().orc_get_step_count(self._h))

@@ -1129,5 +1129,11 @@ int orc_get_episode_info(OrcSim* s, int32_t* steps, uint32_t* episode, uint8_t* 
   if (pose) memcpy(pose, s->pose, s->N);
   return OS2R_OK;
 }
+int orc_set_episode_info(OrcSim* s, const int32_t* steps, const uint32_t* episode, const uint8_t* pose) {
+  if (steps) memcpy(s->steps, steps, s->N * 4);
+  if (episode) memcpy(s->episode, episode, s->N * 4);
+  if (pose) memcpy(s->pose, pose, s->N);
+  return OS2R_OK;
+}
 uint64_t orc_get_step_count(OrcSim* s) { return s->step_count; }
 void orc_set_step_count(OrcSim* s, uint64_t v) { s->step_count = v; }

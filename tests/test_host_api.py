@@ -326,15 +326,19 @@ def test_ctypes_mirror_matches_the_header_as_compiled(tmp_path):
 
 
 def test_vec_env_indices_and_seed_semantics():
-    """HipVecEnv.get_attr / set_attr / env_method with `indices` (common/vec_env/subproc_vec_env.py:125-214), on a
-    stand-in runtime: no GPU involved."""
+    """HipVecEnv.get_attr / set_attr / env_method with `indices` (common/vec_env/subproc_vec_env.py:125-214), on stand-in
+    runtimes: no GPU involved.  An attribute or a method belongs to the batch: a strict subset of the environments is
+    refused (a value recorded for a subset and reported back would not be what the simulation uses, and
+    env_method('reset', indices=[0]) would reset everybody), the whole batch -- also spelled out as indices -- is served."""
     from gym_os2r_amd.common.vec_env import HipVecEnv
 
     class Runtime:
-        num_envs = 6
         observation_space = action_space = None
         color = "red"
         calls = 0
+
+        def __init__(self, n):
+            self.num_envs = n
 
         @property
         def unwrapped(self):
@@ -347,18 +351,48 @@ def test_vec_env_indices_and_seed_semantics():
             self.calls += 1
             return x + 1
 
-    rt = Runtime()
+        def close(self):
+            pass
+
+    rt = Runtime(6)
     vec = HipVecEnv(rt)
     assert vec.get_attr("color") == ["red"] * 6
     assert vec.get_attr("color", indices=[1, 4]) == ["red", "red"] and vec.get_attr("color", indices=2) == ["red"]
-    vec.set_attr("color", "blue", indices=[1, 4])                     # a subset: recorded for those environments
-    assert vec.get_attr("color") == ["red", "blue", "red", "red", "blue", "red"] and rt.color == "red"
+    with pytest.raises(NotImplementedError):
+        vec.set_attr("color", "blue", indices=[1, 4])                 # a subset: refused, nothing recorded
+    assert vec.get_attr("color") == ["red"] * 6 and rt.color == "red"
     vec.set_attr("color", "green")                                    # everybody: the shared runtime's attribute
     assert vec.get_attr("color") == ["green"] * 6 and rt.color == "green"
-    assert vec.env_method("ping", 1, indices=[0, 5]) == [2, 2] and rt.calls == 1
+    vec.set_attr("color", "teal", indices=range(6))                   # everybody, spelled out
+    assert rt.color == "teal"
+    with pytest.raises(NotImplementedError):
+        vec.env_method("ping", 1, indices=[0, 5])
+    assert rt.calls == 0
+    assert vec.env_method("ping", 1) == [2] * 6 and rt.calls == 1
     assert vec.seed(7) == [7] * 6
     with pytest.raises(IndexError):
         vec.get_attr("color", indices=[6])
+    with pytest.raises(RuntimeError):
+        vec.step_wait()                                               # nothing in flight
+    # several shards of one batch: sizes, slices, one call per shard
+    a, b = Runtime(4), Runtime(2)
+    vec2 = HipVecEnv(a, b)
+    assert vec2.num_envs == 6 and vec2.num_splits == 2 and vec2.split_slices == [slice(0, 4), slice(4, 6)]
+    assert vec2.env_method("ping", 3) == [4] * 6 and a.calls == 1 and b.calls == 1
+    vec2.set_attr("color", "grey")
+    assert a.color == b.color == "grey" and vec2.seed(3) == [3] * 6
+    vec2.close()
+
+
+def test_make_mp_envs_cuts_the_batch_into_contiguous_shards():
+    """common.make_mp_envs(..., num_splits=k): shard r gets the balanced contiguous range of distributed.shard_range and
+    its global offset (the key of every random stream): what makes the shards reproduce the single batch."""
+    from gym_os2r_amd import common, randomizers
+    vec = common.make_mp_envs("Monopod-balance-v1", 10, 7, randomizers.monopod.MonopodEnvRandomizer, start_idx=100, num_splits=3)
+    assert [e.num_envs for e in vec.envs] == [4, 3, 3] and vec.num_envs == 10
+    assert [e.unwrapped._opts["env_offset"] for e in vec.envs] == [100, 104, 107]
+    assert all(e.unwrapped._opts["seed"] == 7 for e in vec.envs)
+    assert vec.split_slices == [slice(0, 4), slice(4, 7), slice(7, 10)]
 
 
 def test_gravity_is_drawn_anew_after_num_physics_rollouts(oracle):
