@@ -151,30 +151,34 @@ def load_json(name):
     return None
 
 
-def counted_flops(sim, ck, steps, dr, workload, skip=0):
-    """Replay the timed window from its checkpoint with the counting kernel variant: the work the timed
-    launches did (the rollout is deterministic), priced with profiles/flop_model.json.  -> dict or None."""
-    from gym_os2r_amd import abi
+def counted_flops(sims, cks, steps, dr, workload, skip=0):
+    """Replay the timed window from its checkpoint(s) with the counting kernel variant -- every shard of the batch in turn --:
+    the work the timed launches did (the rollout is deterministic), priced with profiles/flop_model.json.  -> dict or None.
+    `flops_per_launch` is per env-step of the whole batch (all its shards)."""
     from gym_os2r_amd.sim import Os2rError
     model = (load_json("flop_model.json") or {}).get(f"{workload}_f64")
-    try:
-        sim.set_state(ck["q"], ck["qd"])
-        sim.set_action_history(0, ck["hist0"]); sim.set_action_history(1, ck["hist1"])
-        if dr:                                        # (restoring parameters would switch a nominal handle to per-env ones)
-            for f, v in ck["params"].items():
-                sim.set_params(f, v)
-        sim.set_episode_info(ck["steps"], ck["episode"], ck["pose"])
-        sim.step_count = ck["step_count"]
-        if skip:
-            sim.bench_steps(skip)                     # the untimed steps that lay between the checkpoint and the window
-        sim.count_work(True)
-        sim.bench_steps(steps)
-        c = sim.work_counters()
-        sim.count_work(False)
-    except Os2rError:
-        sim.count_work(False)
-        return None                                   # no counting variant for this configuration
-    waves = (sim.N + 63) // 64
+    c, waves = {}, 0
+    for sim, ck in zip(sims, cks):
+        try:
+            sim.set_state(ck["q"], ck["qd"])
+            sim.set_action_history(0, ck["hist0"]); sim.set_action_history(1, ck["hist1"])
+            if dr:                                    # (restoring parameters would switch a nominal handle to per-env ones)
+                for f, v in ck["params"].items():
+                    sim.set_params(f, v)
+            sim.set_episode_info(ck["steps"], ck["episode"], ck["pose"])
+            sim.step_count = ck["step_count"]
+            if skip:
+                sim.bench_steps(skip)                 # the untimed steps that lay between the checkpoint and the window
+            sim.count_work(True)
+            sim.bench_steps(steps)
+            ci = sim.work_counters()
+            sim.count_work(False)
+        except Os2rError:
+            sim.count_work(False)
+            return None                               # no counting variant for this configuration
+        for k_, v_ in ci.items():
+            c[k_] = c.get(k_, 0) + v_
+        waves += (sim.N + 63) // 64
     wi = max(c["wave_iterations"], 1)
     out = {"activity": {"scanned_bodies_per_wave_iteration": c["scanned_bodies"] / wi,
                         "row_bodies_per_wave_iteration": c["row_bodies"] / wi,
@@ -187,9 +191,16 @@ def counted_flops(sim, ck, steps, dr, workload, skip=0):
            "counters": c}
     if model:
         k = model["flops_per_unit"]
-        total = (k["launch_wave"] * waves * steps + k["wave_iteration"] * c["wave_iterations"] + k["scanned_body"] * c["scanned_bodies"]
-                 + k["row_body"] * c["row_bodies"] + k["body_sweep"] * c["body_sweeps"] + k["sweep"] * c["sweeps"])
-        out["flops_per_launch"] = total / steps
+        fixed = k["launch_wave"] * waves * steps + k["wave_iteration"] * c["wave_iterations"] + k["scanned_body"] * c["scanned_bodies"]
+        rows_, sweeps_, solves_ = k["row_body"] * c["row_bodies"], k["body_sweep"] * c["body_sweeps"] + k["sweep"] * c["sweeps"], k.get("exact_solve", 0.0) * c["exact_solves"]
+        out["flops_per_launch"] = (fixed + rows_ + sweeps_ + solves_) / steps
+        # The same work with the masked-off lanes taken out: a wave-instruction of a body's rows is useful for the
+        # lanes in contact with that body, one of a sweep for the lanes still live in it, one of an exact solve for the
+        # lanes that take part; the per-launch and per-iteration parts and the candidate scans run for every lane.
+        live_rows = c["lane_contacts"] / max(64.0 * c["row_bodies"], 1.0)
+        live_sweeps = c["live_lane_sweeps"] / max(64.0 * c["sweeps"], 1.0)
+        live_solves = c["lane_exact_solves"] / max(64.0 * c["exact_solves"], 1.0)
+        out["useful_flops_per_launch"] = (fixed + rows_ * live_rows + sweeps_ * live_sweeps + solves_ * live_solves) / steps
         out["model"] = model.get("source")
     return out
 
@@ -224,10 +235,10 @@ def main():
                     help="process-group backend for the barrier / max-time reduction (nccl = RCCL; gloo lets several "
                          "ranks share one GPU when rehearsing the multi-rank path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--splits", type=int, default=1,
+    ap.add_argument("--splits", type=int, default=4,
                     help="cut this rank's batch into that many contiguous shards, one handle and one stream each, advancing "
                          "independently (a shard waits for its own slowest wave only; DESIGN.md 7).  Results per environment "
-                         "are those of the single batch, bit for bit")
+                         "are those of the single batch, bit for bit.  1: one handle, one launch per env-step of the batch")
     ap.add_argument("--gather-obs", action="store_true",
                     help="also gather obs / reward / done of every step to rank 0 (the optional RCCL collective of "
                          "SURVEY 8e; off the step path, so off by default): one launch + one gather per step")
@@ -245,6 +256,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    if args.gather_obs:
+        args.splits = 1                               # the gather experiment times one launch + one gather per step
+    if args.splits > 1:
+        # one hardware queue per shard stream (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default,
+        # and two shards that share a queue run one after the other: 311 instead of 157 us per step with four shards);
+        # read when the runtime initialises, i.e. before anything below touches the GPU
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * args.splits)))
     import torch
     import torch.distributed as dist
     from gym_os2r_amd.sim import HipSim
@@ -268,8 +286,6 @@ def main():
     if use_dist and dist.get_world_size() != world:
         raise SystemExit(f"WORLD_SIZE={world} but the process group has {dist.get_world_size()} ranks")
     S = max(1, args.splits)
-    if S > 1 and args.gather_obs:
-        raise SystemExit("--splits and --gather-obs are separate experiments")
     cfg, model, spec = build_config(args, rank, world)
     esz = 8 if args.dtype == "f64" else 4
     if S == 1:
@@ -295,10 +311,10 @@ def main():
             if args.warmup > 0:
                 sims[i].bench_enqueue(args.warmup)
     torch.cuda.synchronize()
-    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64" and S == 1
+    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64"
     for _ in range(3 if use_dist else 0):
         barrier()                                     # communicator set-up and first-use costs of the barrier itself stay outside
-    ck = sim.checkpoint() if count else None          # for the counting replay of the timed window
+    cks = [s_.checkpoint() for s_ in sims] if count else None   # for the counting replay of the timed window
     # A GPU that idles just before the window -- through the checkpoint's small copies, or while the host sits in the
     # opening barrier (150-400 us under RCCL) -- has dropped its clock, and the first launches of a short timed window run
     # up to 6 % slow (measured: 145.6 against 137.9 us per launch over 20 steps behind an RCCL barrier).  So a few more
@@ -402,19 +418,26 @@ def main():
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
                          "traffic_source": None if traffic is None else
                          "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " + str(traffic.get("source")) + "; not measured by this run)",
-                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "algorithmic_bytes_per_launch": bytes_launch / S,
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "concurrent_launches": S,
+                         "achieved_per_launch": bytes_launch / S / per_launch_s / 1e9,
                          "note": "ALU-bound path: see roofline_valu" + ("" if S == 1 else f"; {S} shards on {S} streams: a step of the batch is {S} concurrent launches of "
-                                                                          "1/S of the bytes each, kernel_ms_per_launch is the mean launch duration of a shard and `achieved` the rate of all of them together")},
+                                                                          "1/S of the bytes each; kernel_ms_per_launch is the mean launch duration of a shard (HIP events on its stream), "
+                                                                          "achieved_per_launch = algorithmic_bytes_per_launch / kernel_ms_per_launch, and `achieved` = concurrent_launches x that: the rate of the launches in flight together")},
         }
         peak = FP64_VECTOR_PEAK_TF if args.dtype == "f64" else FP32_VECTOR_PEAK_TF
-        cf = counted_flops(sim, ck, args.steps, WORKLOADS[args.workload][3], args.workload, skip=busy_steps) if count else None
+        cf = counted_flops(sims, cks, args.steps, WORKLOADS[args.workload][3], args.workload, skip=busy_steps) if count else None
         if cf and "flops_per_launch" in cf:
             tf = cf["flops_per_launch"] / per_launch_s / 1e12
+            tfu = cf["useful_flops_per_launch"] / per_launch_s / 1e12
             out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                                    "frac": tf / peak, "flops_per_env_step": cf["flops_per_launch"] / args.envs_per_gpu,
-                                    "flops_source": "work of this run's timed window (counting replay from a checkpoint) x " + str(cf["model"]),
+                                    "frac": tf / peak, "issued_lane_flops_per_env_step": cf["flops_per_launch"] / args.envs_per_gpu,
+                                    "achieved_useful": tfu, "frac_useful": tfu / peak,
+                                    "useful_flops_per_env_step": cf["useful_flops_per_launch"] / args.envs_per_gpu,
+                                    "flops_source": "work of this run's timed window (counting replay from a checkpoint) x " + str(cf["model"])
+                                                    + "; `achieved` / `frac` price every wave-instruction as 64 lane operations whatever its exec mask "
+                                                      "(issue slots), `achieved_useful` / `frac_useful` take the masked-off lanes of rows, sweeps and exact solves out",
                                     "activity": cf["activity"]}
         elif cf:
             out["roofline_valu"] = {"bound": "valu_" + args.dtype, "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None,

@@ -15,7 +15,7 @@ os2r_set_work_counters) and prices it with profiles/flop_model.json.  This tool 
 are all in the window, so the regressors vary); `counts` repeats them with the counting kernel, reading the
 counters back after every launch; `fit` aligns the two by launch index and solves, per workload,
       64 * (2*FMA + MUL + ADD)_launch  =  k_launch_wave * waves + k_scanned_body * scanned + k_row_body * rows
-                                          + k_body_sweep * body_sweeps + k_sweep * sweeps
+                                          + k_body_sweep * body_sweeps + k_sweep * sweeps + k_exact_solve * exact_solves
 by non-negative least squares (PMC counts wave-instructions; a wave-instruction is priced as 64 lane operations whatever its
 exec mask: issued flops).  The physics-iteration count per launch is fixed (10), so its price is inside
 k_launch_wave.  The report gives the residual of the fit per launch.
@@ -93,13 +93,13 @@ def fit(src, dst):
         y = 64.0 * (2 * np.array(pmc["SQ_INSTS_VALU_FMA_F64"][:n]) + np.array(pmc["SQ_INSTS_VALU_MUL_F64"][:n])
                     + np.array(pmc["SQ_INSTS_VALU_ADD_F64"][:n]))
         waves = (counts["envs"] + 63) // 64
-        X = np.array([[waves, c["scanned_bodies"], c["row_bodies"], c["body_sweeps"], c["sweeps"]] for c in L[:n]], dtype=float)
+        X = np.array([[waves, c["scanned_bodies"], c["row_bodies"], c["body_sweeps"], c["sweeps"], c.get("exact_solves", 0)] for c in L[:n]], dtype=float)
         from scipy.optimize import nnls
-        scale = X.max(axis=0)
+        scale = np.maximum(X.max(axis=0), 1.0)
         k, _ = nnls(X / scale, y)          # prices cannot be negative (the regressors are correlated in time)
         k = k / scale
         res = (X @ k - y) / y
-        names = ["launch_wave", "scanned_body", "row_body", "body_sweep", "sweep"]
+        names = ["launch_wave", "scanned_body", "row_body", "body_sweep", "sweep", "exact_solve"]
         out[wl + "_f64"] = {"flops_per_unit": dict(zip(names, k.tolist()), wave_iteration=0.0),
                             "fit": {"launches": int(n), "rel_residual_rms": float(np.sqrt((res ** 2).mean())),
                                     "rel_residual_max": float(np.abs(res).max()),

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/flopmodel
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-for w in C4 C3 V1; do
+for w in ${FLOP_WORKLOADS:-C4 C3 V1}; do
   cd "$ROOT"
   timeout -k 10 300 python tools/flop_model.py counts --workload $w --steps 1200 --out "$OUT/counts_$w.json"; echo "counts $w rc=$?"
   cd /tmp
