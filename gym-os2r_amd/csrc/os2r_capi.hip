@@ -105,6 +105,7 @@ struct SimBase {
   unsigned long long* counters = nullptr;   // caller-owned work-counter buffer (os2r_set_work_counters)
   uint8_t* b_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint16_t* reason = nullptr;           // caller-owned done-reason buffer (os2r_set_done_reasons)
   unsigned long long* debug = nullptr;  // diagnostic stamp builds only
 };
 
@@ -259,6 +260,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
   a.steps = s->steps; a.episode = s->episode; a.pose = s->pose; a.violations = s->violations;
   a.debug = s->debug;
+  a.reason = s->reason;
   task_layout(s->cfg.task, a.layout_kinds, a.layout_srcs, a.layout_dim);
   return a;
 }
@@ -602,6 +604,12 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) 
 int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev) {
   if (!sim) return OS2R_ERR_INVALID;
   sim->counters = (unsigned long long*)counters_dev;
+  return OS2R_OK;
+}
+
+int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev) {
+  if (!sim) return OS2R_ERR_INVALID;
+  sim->reason = reason_dev;
   return OS2R_OK;
 }
 

@@ -167,6 +167,7 @@ struct StepArgs {
   const uint8_t* __restrict__ reset_mask;  // reset kernel only
   unsigned long long* __restrict__ debug;  // diagnostic stamp builds only (else null)
   unsigned long long* __restrict__ counters;  // work counters of the counting kernel variants (os2r_set_work_counters), else null
+  uint16_t* __restrict__ reason;              // [N] which observation slots left the reset space in this step (os2r_set_done_reasons), else null
   // host side of the launch only: the observation layout of the handle's task, 4 bits per slot (slot 0 lowest),
   // compared with the layouts that exist as compile-time variants of the step kernel
   unsigned long long layout_kinds, layout_srcs;
@@ -582,9 +583,12 @@ __device__ __forceinline__ bool for_body(int b, F&& f) {
   }
 }
 
-// EXACT_ONLY: the exact finish is known to be on (pgs_exact > 0, fixed box): the grouped sweeps of the round-1/2 solver are
-// not instantiated (the kernels with the default solver settings)
-template <typename T, typename MD, bool CONTACT, bool DR, bool COUNT = false, bool EXACT_ONLY = false>
+// SOLVER: which phase-2 solver(s) the kernel carries -- kSolverBoth: chosen at run time by pgs_exact (run-time code objects
+// built without knowing the handle's settings); kSolverExact: the exact finish (pgs_exact > 0, fixed box), the grouped
+// sweeps of the round-1/2 solver are not instantiated; kSolverSweeps: sweeps only (every fp32 kernel; fp64 with pgs_exact = 0).
+// One solver per kernel keeps the 5-dof fp64 kernels inside the register file.
+enum { kSolverBoth = 0, kSolverExact = 1, kSolverSweeps = 2 };
+template <typename T, typename MD, bool CONTACT, bool DR, bool COUNT = false, int SOLVER = kSolverBoth>
 __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& par,
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T (&sn)[MD::NQ], T (&cs)[MD::NQ], bool first_iteration,
                                         T tau_hip, T tau_knee, T dt, T erp,
@@ -922,7 +926,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // only the change of y is mapped back, so an idle solve leaves v bit-identical.  The start value waits in registers in
   // the kernels built for the default solver settings, in per-lane LDS slots in the others (their register file is full
   // during the exact solves, see kMuInLds below)
-  constexpr bool kParkY0 = sizeof(T) == 8 && !EXACT_ONLY;
+  constexpr bool kStdExact = sizeof(T) == 8 && SOLVER == kSolverExact && MD::kStatic;   // the kernels that have registers to spare
+  constexpr bool kParkY0 = sizeof(T) == 8 && SOLVER != kSolverSweeps && !kStdExact;
   constexpr int kY0Slot = NQ * (NQ + 1) / 2 + 3 * NQ + NQ;   // behind the factor's mirror and the multipliers' slots
   static_assert(kY0Slot + NQ <= 8 * NQ, "per-lane LDS slots");
   T y0[NQ];
@@ -1386,7 +1391,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // The multipliers wait between the passes: in registers in the kernels built for the default solver settings, in
     // free per-lane LDS slots (behind the factor's mirror) in the others, whose register file is full -- they also
     // carry the sweeps-only solver and, for run-time models, rows for every body (scratch otherwise: 12-370 B per lane)
-    constexpr bool kMuInLds = !EXACT_ONLY;
+    constexpr bool kMuInLds = !kStdExact;
     constexpr int kMuSlot = NQ * (NQ + 1) / 2;
     static_assert(kMuSlot + 3 * NB + NQ <= 8 * NQ, "per-lane LDS slots");
     T mu_reg[kMuInLds ? 1 : 3 * NB + NQ];
@@ -1514,9 +1519,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_STAMP(7);
 #pragma unroll
     for (int b = 0; b < NB; ++b) limfix[b] = opaque(mub[b] * ln[b]);   // (a plain value: the exact finish subtracts from it)
-    if constexpr (sizeof(T) == 8 && EXACT_ONLY) {
+    if constexpr (sizeof(T) == 8 && SOLVER == kSolverExact) {
       exact_sweeps(first);
-    } else if constexpr (sizeof(T) == 8) {
+    } else if constexpr (sizeof(T) == 8 && SOLVER == kSolverBoth) {
       if (pgs_exact > 0) exact_sweeps(first);
       else grouped_sweeps(std::false_type{}, first);
     } else {

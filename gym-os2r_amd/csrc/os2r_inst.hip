@@ -78,10 +78,16 @@ static int launch_step(const StepArgs<T>& a, hipStream_t s) {
     }
 #endif
     if (a.counters) return 1;
-    OS2R_LAUNCH(MD::kStatic);
+    if constexpr (MD::kStatic) { OS2R_LAUNCH(true); }     // (run-time models never get here: nothing to instantiate for them)
   } else {
     if (a.counters) return 1;
-    OS2R_LAUNCH(false);
+    // other solver settings: a kernel per solver (fp64: exact finish or sweeps only; fp32: sweeps only)
+    if constexpr (sizeof(T) == 8) {
+      if (a.pgs_exact > 0) hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, false, RtLayout, false, kSolverExact>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, false, RtLayout, false, kSolverSweeps>), grid, block, 0, s, a);
+    } else {
+      OS2R_LAUNCH(false);
+    }
   }
   return 0;
 }

@@ -88,9 +88,10 @@ constexpr unsigned long long pack_layout(const int* v, int n) {
 
 template <typename T, int NQ, typename LAY = RtLayout>
 __device__ __forceinline__ void observe(TaskPtr<T> ts, const T (&q)[NQ], const T (&qd)[NQ],
-                                        T h1a, T h1b, T (&obs)[OS2R_MAX_OBS], bool& done) {
+                                        T h1a, T h1b, T (&obs)[OS2R_MAX_OBS], bool& done, unsigned& reason) {
 #pragma clang fp contract(off)
   done = false;
+  reason = 0u;   // bit d: observation slot d is outside the reset space (or not finite): which one ended the episode
   int D = LAY::kStatic ? LAY::kDim : ts->obs_dim;
   if constexpr (!LAY::kStatic) asm volatile("" : "+s"(D));   // one copy in a register: not re-fetched (and waited for) slot after slot
   // The slots' constants are fetched four slots at a time, ahead of the slots' arithmetic: left to the
@@ -137,7 +138,7 @@ __device__ __forceinline__ void observe(TaskPtr<T> ts, const T (&q)[NQ], const T
       if (kind == OS2R_OBS_POS_PERIODIC_NORM || kind == OS2R_OBS_POS_PERIODIC_RAW) x = wrap_pi(x);
       // done: the reference tests the observation against reset_space; done_lo/done_hi are the
       // exact pre-images of that test on x (host-side bisection), NaN counts as done
-      if (x < dlo_[k] || x > dhi_[k] || !finite_t(x)) done = true;   // NaN counts as done
+      if (x < dlo_[k] || x > dhi_[k] || !finite_t(x)) { done = true; reason |= 1u << d; }   // NaN counts as done
       T o = x;
       if (kind == OS2R_OBS_POS_NORM || kind == OS2R_OBS_POS_PERIODIC_NORM || kind == OS2R_OBS_TORQUE_NORM) {
         const T lo = lo_[k], hi = hi_[k];
@@ -401,7 +402,12 @@ __device__ __forceinline__ MD make_model(const StepArgs<T>& A) {
 // COUNT: the counting variant (os2r_set_work_counters): same arithmetic, and the wave's work of the launch is added to
 // A.counters[0..kWorkCounters) by one lane at the end.
 constexpr int kWorkCounters = OS2R_NUM_WORK_COUNTERS;
-template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false, typename LAY = RtLayout, bool COUNT = false>
+// SOLVER (os2r_device.hpp): kSolverBoth unless the launcher knows the handle's solver
+constexpr int std_solver(bool std_sweeps, bool is_f64, bool std_exact) {
+  return !is_f64 ? kSolverSweeps : (std_sweeps ? (std_exact ? kSolverExact : kSolverSweeps) : kSolverBoth);
+}
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false, typename LAY = RtLayout, bool COUNT = false,
+          int SOLVER = std_solver(STD_SWEEPS, sizeof(T) == 8, StdSolver<T>::kExact)>
 __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
   // run-time models scan a wave-shared LDS copy of the candidate table; the compiled-in ones read the
@@ -468,7 +474,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   WorkCounts wc;
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR, COUNT, STD_SWEEPS && StdSolver<T>::kExact>(
+    substep<T, MD, CONTACT, DR, COUNT, SOLVER>(
                                        md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
                                        STD_SWEEPS ? StdSolver<T>::kIters : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
                                        A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc
@@ -495,8 +501,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
   T obs[OS2R_MAX_OBS];
   bool dn;
+  unsigned why;
   OS2R_STAMP(20);
-  observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn);
+  observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn, why);
   OS2R_STAMP(21);
   const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
   OS2R_STAMP(22);
@@ -517,7 +524,8 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
       epi += 1;
       steps = 0;
       bool dn2;
-      observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn2);
+      unsigned why2;
+      observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn2, why2);
     }
   }
   if (A.obs) store_obs_tile<T>(A.obs, obs, D, e0, A.N, lane, tile);
@@ -541,6 +549,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     }
     if (A.reward) A.reward[e] = rew;
     if (A.done) A.done[e] = flag;
+    if (A.reason) A.reason[e] = (uint16_t)why;
   }
 #ifdef OS2R_STAMPS
   stamps[11] = __builtin_amdgcn_s_memtime() - stamp_prev;   // the state and flag stores, issued
@@ -561,9 +570,10 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #define OS2R_STEP_KERNEL_ATTRS(REAL) \
   __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
 
-template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS, typename LAY = RtLayout, bool COUNT = false>
+template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS, typename LAY = RtLayout, bool COUNT = false,
+          int SOLVER = std_solver(STD_SWEEPS, sizeof(T) == 8, StdSolver<T>::kExact)>
 __global__ OS2R_STEP_KERNEL_ATTRS(T) void step_kernel(const StepArgs<T> A) {
-  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY, COUNT>(A);
+  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY, COUNT, SOLVER>(A);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -595,7 +605,8 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const StepArgs<T> A) {
   const T h1x = A.hist[2 * A.N + e], h1y = A.hist[3 * A.N + e];
   T obs[OS2R_MAX_OBS];
   bool dn;
-  observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn);
+  unsigned why;
+  observe<T, NQ>(ts, q, qd, h1x, h1y, obs, dn, why);
   if (A.obs) store_obs_tile<T>(A.obs, obs, ts->obs_dim, e0, A.N, lane, tile);
   if (valid && doit) {
 #pragma unroll

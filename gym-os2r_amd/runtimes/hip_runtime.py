@@ -93,7 +93,7 @@ class HipRuntime:
                  num_envs: int = 1, device=None, seed: int = 0, dtype: str = "f64",
                  contact: bool = True, max_episode_steps: int = 0, env_offset: int = 0,
                  pgs_iters: Optional[int] = None, pgs_normal_iters: int = 3, pgs_exact: Optional[int] = None,
-                 pgs_tol: Optional[float] = None, auto_reset: bool = True,
+                 pgs_tol: Optional[float] = None, auto_reset: bool = True, done_reasons: bool = False,
                  physics_engine=None, world: Optional[str] = None, **kwargs):
         steps = physics_rate / agent_rate
         if steps != int(steps):
@@ -113,7 +113,10 @@ class HipRuntime:
                           # `pgs_tol` [J] is the stopping tolerance of the sweeps, 1e-24 in fp64 and 1e-13 in fp32)
                           pgs_iters=None if pgs_iters is None else int(pgs_iters), pgs_normal_iters=int(pgs_normal_iters),
                           pgs_exact=None if pgs_exact is None else int(pgs_exact),
-                          pgs_tol=None if pgs_tol is None else float(pgs_tol), auto_reset=bool(auto_reset))
+                          pgs_tol=None if pgs_tol is None else float(pgs_tol), auto_reset=bool(auto_reset),
+                          # info['done_reason']: which observation ended each episode (the reference's debug line,
+                          # tasks/monopod.py:288-296, as a bitmask per environment; `done_reason_names` decodes it)
+                          done_reasons=bool(done_reasons))
         # set by the randomizer wrappers before the first reset (randomizers/*.py)
         self._reset_mode = abi.RESET_FIXED
         self._randomize_params = False
@@ -162,6 +165,8 @@ class HipRuntime:
                                     pgs_normal_iters=o["pgs_normal_iters"], pgs_exact=o["pgs_exact"],
                                     pgs_tol=o["pgs_tol"], auto_reset=o["auto_reset"])
             self._sim = HipSim(cfg, device=o["device"])
+            if o["done_reasons"]:
+                self._sim.done_reasons(True)
             self._bad_seen, self._bad_pending = 0, [False, False]     # a new handle counts from zero
         return self._sim
 
@@ -219,9 +224,11 @@ class HipRuntime:
             h1 = sim.get_action_history(1).cpu().numpy()
             vals = [float(self.task.calculate_reward(o_np[i], [h0[:, i], h1[:, i]])) for i in range(self.num_envs)]
             rew = torch.as_tensor(vals, dtype=rew.dtype, device=rew.device)
-        info = BatchedInfo(done_flags=flags, terminal_observation=term,
-                           lazy={"reset_orientation_id": lambda: sim.episode_info()[2],
-                                 "truncated": lambda: (flags & abi.TRUNCATED_BIT).bool()})
+        lazy = {"reset_orientation_id": lambda: sim.episode_info()[2],
+                "truncated": lambda: (flags & abi.TRUNCATED_BIT).bool()}
+        if sim.reasons is not None:
+            lazy["done_reason"] = lambda: sim.reasons.clone()      # bit d: observation d left the reset space
+        info = BatchedInfo(done_flags=flags, terminal_observation=term, lazy=lazy)
         return obs, rew, flags != 0, info
 
     def _raise_if_bad_actions(self, drain: bool = False):
@@ -240,6 +247,11 @@ class HipRuntime:
                     self._bad_seen = max(int(self._bad_flag[k]), int(self._bad_flag[o]))
                     raise AssertionError("invalid: actions of an earlier step() left the action space [-1, 1] "
                                          "(they were clamped, as the backend clamps the torque)")
+
+    def done_reason_names(self, mask: int):
+        """The observation names behind a `done_reason` bitmask (what tasks/monopod.py:288-296 logs in the reference)."""
+        names = sorted(self.task.observation_index, key=self.task.observation_index.get)
+        return [n for d, n in enumerate(names) if (int(mask) >> d) & 1]
 
     def get_state_info(self, obs, actions):
         """(reward, done) recomputed on the host for one observation (tasks/monopod.py:348-366)."""

@@ -93,6 +93,9 @@ class _PybindLib:
     def os2r_set_work_counters(self, h, buf):
         return self.m.set_work_counters(self._a(h), self._a(buf))
 
+    def os2r_set_done_reasons(self, h, buf):
+        return self.m.set_done_reasons(self._a(h), self._a(buf))
+
     def os2r_last_error(self, h):
         return self.m.last_error(self._a(h)).encode()
 
@@ -122,6 +125,7 @@ class HipSim:
         from . import jit
         self.specialised = jit.specialise(_lib.load(), cfg)
         self._counters = None                         # count_work(True) allocates the work counters
+        self.reasons = None                           # done_reasons(True) allocates the done-reason output
         self._h = C.c_void_p()
         rc = self._lib.os2r_create(C.byref(cfg), C.byref(self._h))
         if rc != abi.OK:
@@ -186,6 +190,16 @@ class HipSim:
         ms = C.c_float()
         self._check(self._lib.os2r_bench_steps(self._h, int(nsteps), self._stream(), C.byref(ms)), "os2r_bench_steps")
         return float(ms.value)
+
+    def done_reasons(self, on: bool = True):
+        """Switch the done-reason output on (include/os2r.h: os2r_set_done_reasons) or off.  While on, `self.reasons`
+        ([N] int16: bit d = observation slot d was outside the reset space at the end of the last step) is rewritten by
+        every step; -> the tensor (the same one every step) or None."""
+        new = torch.zeros(self.N, dtype=torch.int16, device=self.device) if on else None
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check(self._lib.os2r_set_done_reasons(self._h, _ptr(new)), "os2r_set_done_reasons")
+        self.reasons = new
+        return new
 
     def bench_enqueue(self, nsteps: int):
         """Enqueue nsteps random-action steps on the current stream and return at once (no events, no wait): for

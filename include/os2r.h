@@ -289,6 +289,13 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
 #define OS2R_NUM_WORK_COUNTERS 10
 int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
 
+/* Done reasons (replaces the debug line that names the observation which caused a reset,
+ * gym_os2r/tasks/monopod.py:288-296): while a buffer of num_envs uint16 (device memory) is set, every os2r_step
+ * writes per environment which observation slots were outside the reset space at the end of the step -- bit d:
+ * slot d of the task's observation layout (a non-finite value counts) -- i.e. what set bit0 of `done`; 0 for an
+ * environment that is not done or only truncated.  NULL switches it off.                                       */
+int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev);
+
 const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */
 
 #ifdef __cplusplus

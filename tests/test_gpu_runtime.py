@@ -496,7 +496,7 @@ def test_one_rccl_rank_runs_the_distributed_bracket_of_the_bench(tmp_path):
     import json
     import subprocess
     import sys
-    for extra in ([], ["--gather-obs"], ["--splits", "4"]):
+    for extra in ([], ["--gather-obs"], ["--splits", "1"]):
         env = dict(os.environ, MASTER_PORT="29541", MASTER_ADDR="127.0.0.1", OS2R_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--steps", "20", "--warmup", "5",
                "--preroll", "50", "--no-cpu-baseline", "--no-count"] + extra
@@ -504,6 +504,49 @@ def test_one_rccl_rank_runs_the_distributed_bracket_of_the_bench(tmp_path):
         assert r.returncode == 0, (extra, r.stderr[-2000:])
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert d["n_gpus"] == 1 and d["config"]["n_ranks_seen"] == 1 and d["config"]["total_envs"] == 65536
-        assert d["config"]["splits"] == (4 if "--splits" in extra else 1)
+        assert d["config"]["splits"] == (4 if not extra else 1)       # the default: four shards; the gather experiment and --splits 1: one
         assert d["value"] == pytest.approx(65536 * 20 / (d["ms_per_step"] * 1e-3 * 20), rel=1e-6)
         assert 0 < d["roofline"]["kernel_ms_per_launch"] and d["roofline"]["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.5
+
+
+def test_done_reasons_name_the_observation_that_ended_the_episode(torch_mod):
+    """os2r_set_done_reasons / HipRuntime(done_reasons=True): info['done_reason'] carries, per environment, the bitmask of
+    the observation slots that left the reset space in this step -- what the reference logs as text
+    (gym_os2r/tasks/monopod.py:288-296).  Checked against the terminal observation and the task's own reset space on
+    the host: bit d is set where component d is outside [low, high] and clear where it is inside (up to the 2 ulp of the
+    kernel's tanh at the boundary); an environment that is not done, or only truncated, reports 0."""
+    n = 512
+    # contact off and a constant full torque on half of the environments: the free lower leg spins up until its velocity
+    # observation leaves the reset space (tanh(0.05 v) > 1 - eps at |v| ~ 370 rad/s, ~140 env-steps); the others draw random
+    # actions and are truncated by the TimeLimit instead
+    make_env = functools.partial(make_env_from_id, env_id="Monopod-balance-v1", num_envs=n, task_mode="fixed_hip", done_reasons=True,
+                                 max_episode_steps=170, contact=False)
+    env = MonopodEnvRandomizer(env=make_env)
+    env.seed(3); env.reset()
+    rt = env.unwrapped
+    lo, hi = rt.task.reset_space.low, rt.task.reset_space.high
+    seen = set()
+    gen = torch_mod.Generator(device="cuda").manual_seed(1)
+    for t in range(400):
+        a = torch_mod.rand(n, 2, generator=gen, device="cuda", dtype=torch_mod.float64) * 2 - 1
+        a[: n // 2] = 1.0
+        obs, rew, done, info = env.step(a)
+        reason = info["done_reason"].cpu().numpy().astype(np.int64) & 0xffff
+        term = info["terminal_observation"].cpu().numpy()
+        flags = info["done_flags"].cpu().numpy()
+        # The kernel tests the value before the tanh / affine map against the exact pre-image of the reset space; the
+        # terminal observation carries the mapped value, whose tanh may differ from glibc's by 2 ulp -- right at
+        # 1 - eps, where the velocity observations end an episode.  So: clearly outside => bit set, clearly inside => clear.
+        slack = 4 * np.finfo(np.float64).eps
+        must = np.zeros(n, dtype=np.int64); may = np.zeros(n, dtype=np.int64)
+        for d in range(term.shape[1]):
+            must |= ((term[:, d] < lo[d] - slack) | (term[:, d] > hi[d] + slack)).astype(np.int64) << d
+            may |= (~((term[:, d] > lo[d] + slack) & (term[:, d] < hi[d] - slack))).astype(np.int64) << d
+        assert np.array_equal(reason & must, must) and np.array_equal(reason & ~may, np.zeros(n, dtype=np.int64)), t
+        assert np.array_equal(reason != 0, (flags & abi.DONE_BIT) != 0)
+        seen |= set(int(r) for r in reason[reason != 0])
+    assert seen, "no episode ended: the test did not exercise a reason"
+    some = next(iter(seen))
+    names = rt.done_reason_names(some)
+    assert names and all(nm in rt.task.observation_index for nm in names)
+    env.close()

@@ -28,14 +28,14 @@ $B --dtype f32 > "$OUT/bench_f32_64k.json" 2>/dev/null; show "$OUT/bench_f32_64k
 $B --dtype f32 --envs-per-gpu 131072 --steps 500 > "$OUT/bench_f32_128k.json" 2>/dev/null; show "$OUT/bench_f32_128k.json"
 $B --dtype f32 --envs-per-gpu 262144 --steps 300 > "$OUT/bench_f32_256k.json" 2>/dev/null; show "$OUT/bench_f32_256k.json"
 OS2R_CLOCK_JSON="$OUT/clock.json" timeout -k 10 200 python tools/dbg/stamps.py C4 1100 > "$OUT/stamps.txt" 2>&1; grep -E "clock|stamp build|per-wave" "$OUT/stamps.txt"
-rm -rf gpurun_out/prof_r02
-bash tools/profile.sh r02 --no-count > "$OUT/profile.log" 2>&1; echo "profile rc=$?"
-bash tools/profile_issue.sh r02 --no-count > "$OUT/profile_issue.log" 2>&1; echo "profile_issue rc=$?"
-python tools/summarize_profile.py gpurun_out/prof_r02 "$OUT/r02_step_kernel_f64_C4" step_kernel "$OUT/traffic.json" "$OUT/clock.json" > /dev/null
-python tools/issue_breakdown.py "$OUT/r02_step_kernel_f64_C4.json" "$OUT/r02_issue_breakdown" > /dev/null 2>&1; echo "issue rc=$?"
+rm -rf gpurun_out/prof_r03
+bash tools/profile.sh r03 --no-count > "$OUT/profile.log" 2>&1; echo "profile rc=$?"
+bash tools/profile_issue.sh r03 --no-count > "$OUT/profile_issue.log" 2>&1; echo "profile_issue rc=$?"
+python tools/summarize_profile.py gpurun_out/prof_r03 "$OUT/r03_step_kernel_f64_C4" step_kernel "$OUT/traffic.json" "$OUT/clock.json" > /dev/null
+python tools/issue_breakdown.py "$OUT/r03_step_kernel_f64_C4.json" "$OUT/r03_issue_breakdown" > /dev/null 2>&1; echo "issue rc=$?"
 timeout -k 10 300 python tools/flop_model.py counts --workload C4 --steps 1200 --out "$OUT/flopmodel/counts_C4.json"; echo "counts rc=$?"
 cd /tmp
 timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU SQ_WAVES --output-format csv -d "$OUT/flopmodel/pmc_C4" -- python3 "$ROOT/tools/flop_model.py" run --workload C4 --steps 1200 > "$OUT/flopmodel/pmc.log" 2>&1; echo "pmc rc=$?"
 cd "$ROOT"; python tools/flop_model.py fit "$OUT/flopmodel" "$OUT/flop_model" | tail -12
 rm -rf "$OUT/flopmodel/pmc_C4"   # (large; the fit is what is kept)
-sed -n 1,30p "$OUT/r02_step_kernel_f64_C4.md"
+sed -n 1,30p "$OUT/r03_step_kernel_f64_C4.md"
