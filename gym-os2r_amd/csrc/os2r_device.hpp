@@ -52,7 +52,10 @@ constexpr int kPgsGroup = 4;
 // sweeps an environment that has not converged solves its free rows exactly -- (S + eps I) d = -G_F^T w_F with
 // S = G_F^T G_F (NQ x NQ whatever the number of free rows), eps = kExactEps * trace S, kExactProx proximal iterations,
 // impulses from the residuals -- cuts the step at the first bound it meets, and re-tests every row with one measured sweep.
-constexpr int kExactFirst = 3, kExactProx = 3;
+#ifndef OS2R_EXACT_FIRST   // (overridden in timing experiments only: tools/sessions/r3_first_sweeps.sh)
+#define OS2R_EXACT_FIRST 4
+#endif
+constexpr int kExactFirst = OS2R_EXACT_FIRST, kExactProx = 3;
 constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;
 
 // Work done by one wave in one physics iteration, for the counting kernel variants (wave-uniform values).

@@ -635,7 +635,7 @@ static int g_row_order = 0;
 void orc_set_experimental_row_order(int order) { g_row_order = order; }
 
 /* ---- exact finish of the fixed-box problem (cfg->pgs_exact) ----
- * Gauss-Seidel identifies the active set of most problems within three sweeps and then crawls on the few whose rows
+ * Gauss-Seidel identifies the active set of most problems within a few sweeps and then crawls on the few whose rows
  * are nearly collinear in the whitened metric (contraction 0.9 per sweep) or degenerate (a sticking foot plus sticking
  * joints: eight rows in five dof).  An environment that has not converged after ORC_EXACT_FIRST sweeps therefore
  * solves its FREE rows (strictly inside their box) exactly, all other rows held at their bounds:
@@ -648,7 +648,7 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
  * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
  * row and measures what it moved.  At most `exact` solves per physics iteration; the sweep cap `iters` still holds. */
-#define ORC_EXACT_FIRST 3
+#define ORC_EXACT_FIRST 4
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX 3
 #define ORC_EXACT_SNAP 1e-12
