@@ -235,10 +235,11 @@ def main():
                     help="process-group backend for the barrier / max-time reduction (nccl = RCCL; gloo lets several "
                          "ranks share one GPU when rehearsing the multi-rank path)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--splits", type=int, default=4,
+    ap.add_argument("--splits", type=int, default=1,
                     help="cut this rank's batch into that many contiguous shards, one handle and one stream each, advancing "
                          "independently (a shard waits for its own slowest wave only; DESIGN.md 7).  Results per environment "
-                         "are those of the single batch, bit for bit.  1: one handle, one launch per env-step of the batch")
+                         "are those of the single batch, bit for bit.  Pays over long rollouts, once the shards have drifted out of "
+                         "phase (+7 % with 4 shards over 1000 steps, nothing over 20); default 1: one handle, one launch per env-step")
     ap.add_argument("--gather-obs", action="store_true",
                     help="also gather obs / reward / done of every step to rank 0 (the optional RCCL collective of "
                          "SURVEY 8e; off the step path, so off by default): one launch + one gather per step")
@@ -329,15 +330,11 @@ def main():
         # every shard's K launches go to its own stream (enqueue only: the host does not wait in between); the
         # shard's launches run back to back there, so its events give its average launch duration
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(S)]
-        chunk = 50                                    # interleave the enqueueing so that no stream starts far behind
-        for k0 in range(0, args.steps, chunk):
-            for i in range(S):
-                with on(i):
-                    if k0 == 0:
-                        evs[i][0].record()
-                    sims[i].bench_enqueue(min(chunk, args.steps - k0))
-                    if k0 + chunk >= args.steps:
-                        evs[i][1].record()
+        for i in range(S):
+            evs[i][0].record(streams[i])
+        HipSim.bench_enqueue_shards(sims, streams, args.steps)   # round robin in C: every stream starts within microseconds
+        for i in range(S):
+            evs[i][1].record(streams[i])
         torch.cuda.synchronize()
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / S   # mean over the shards of (K launches of that shard)
     elif not args.gather_obs:

@@ -9,8 +9,8 @@ vec_env.py:32-245) that a trainer calls.  The per-process Pipe protocol is repla
   previous batch, ...) while the physics runs.
 * ``num_splits > 1``: the batch is cut into contiguous shards, one runtime (one C-ABI handle) and one stream each.  The
   shards advance independently -- a shard waits for its own slowest wave only, and the SIMDs that one shard's early
-  waves leave idle take the next launch of another (+5 % with two, +9 % with four shards at 65 536 environments,
-  DESIGN.md 7) -- and can be driven one at a time (``step_async(a, split=i)`` / ``step_wait(split=i)``): a policy evaluates
+  waves leave idle take the next launch of another (+5 % with two, +7 % with four shards at 65 536 environments over
+  long rollouts, once the shards have drifted out of phase) -- and can be driven one at a time (``step_async(a, split=i)`` / ``step_wait(split=i)``): a policy evaluates
   shard A while the physics of shard B runs (examples/batched_rollout.py --splits).  Random streams are keyed by the global
   environment index, so the shards reproduce the single-handle batch bit for bit.
 """

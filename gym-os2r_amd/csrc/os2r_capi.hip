@@ -601,6 +601,19 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) 
   return OS2R_OK;
 }
 
+int os2r_bench_steps_multi(Os2rSim* const* sims, void* const* streams, int count, int nsteps) {
+  if (!sims || !streams || count < 1 || nsteps < 1) return OS2R_ERR_INVALID;
+  for (int i = 0; i < count; ++i)
+    if (!sims[i]) return OS2R_ERR_INVALID;
+  for (int k = 0; k < nsteps; ++k)
+    for (int i = 0; i < count; ++i) {
+      Os2rSim* s = sims[i];
+      int rc = os2r_step(s, nullptr, s->b_obs, s->b_rew, s->b_done, s->b_term, streams[i]);
+      if (rc) return rc;
+    }
+  return OS2R_OK;
+}
+
 int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev) {
   if (!sim) return OS2R_ERR_INVALID;
   sim->counters = (unsigned long long*)counters_dev;

@@ -1221,13 +1221,16 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
     joint_rows(false);
   };
-  auto sweep = [&](auto coupled, auto first, auto measure_) {
+  // live_only: the sweep runs under the mask of a few lanes (the exact finish's loop): a body that none of them touches
+  // has reciprocals 0 in all of them -- its rows would reproduce themselves -- and is skipped
+  auto sweep = [&](auto coupled, auto first, auto measure_, bool live_only = false) {
     constexpr bool measure = decltype(measure_)::value;
     constexpr int kFirst = decltype(first)::value;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+      if (live_only && __ballot(dn[b] > T(0)) == 0ull) continue;
       contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false, measure);
       if (decltype(coupled)::value) limfix[b] = mub[b] * ln[b];   // the coupled pyramid, experiments only
       const T lim = limfix[b];
@@ -1313,10 +1316,15 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
     for (int k = 0; k < NQ; ++k) h[k] = T(0);
     // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
+    // A row that is free for none of the lanes at work here -- typically two or three of the 64 -- adds exact zeros to S
+    // and h, has mu = 0 and keeps its impulse: the wave skips it in every pass (void for every lane, so a lane's result
+    // does not depend on its company).
     each_row(first, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper, T) {
+      const bool fr = is_free(l, lo, hi, upper);
+      if (__ballot(fr) == 0ull) return;
       // the row's weight as a number the optimiser cannot see through: it would turn the products below back into
       // selects of every entry (two v_cndmask per double) or into a branch around the row
-      const T f = opaque(is_free(l, lo, hi, upper) ? T(1) : T(0));
+      const T f = opaque(fr ? T(1) : T(0));
       T w = -target;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
@@ -1402,7 +1410,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     auto mu_get = [&](int slot) -> T { if constexpr (kMuInLds) return L(kMuSlot + slot); else return mu_reg[slot]; };
     bool cut = false;
     each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper, T) {
-      const T f = opaque(is_free(l, lo, hi, upper) ? ieps : T(0));
+      const bool fr = is_free(l, lo, hi, upper);
+      if (__ballot(fr) == 0ull) return;
+      const T f = opaque(fr ? ieps : T(0));
       T w = -target;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
@@ -1422,6 +1432,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     if (__ballot(cut) != 0ull) {
       T a = T(1);
       each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+        if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         const T m = mu_get(slot);
         const bool up = m > T(0);
         const bool bounded = (m < T(0)) | (upper ? up : false);
@@ -1437,6 +1448,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int i = 0; i < NQ; ++i) y[i] = fma_t(alpha, d[i], y[i]);
     if (__ballot(cut) != 0ull) {
       each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+        if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         const T m = mu_get(slot);
         T nl = fma_t(alpha, m, l);
         const bool at_hi = cut & (upper ? ((m > T(0)) & ((hi - nl) <= T(kExactSnap) * (hi - l))) : false);
@@ -1449,6 +1461,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       });
     } else {
       each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+        if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         T nl = l + mu_get(slot);
         nl = fmax_t(nl, lo);
         if (upper) nl = fmin_t(nl, hi);
@@ -1504,7 +1517,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       }
       if (do_sweep) {
         moved = T(0);
-        sweep(std::false_type{}, first, std::true_type{});
+        sweep(std::false_type{}, first, std::true_type{}, true);
         ++sweeps;
         live = moved > tol_v && sweeps < pgs_iters;
       }

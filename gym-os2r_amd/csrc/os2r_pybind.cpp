@@ -4,6 +4,7 @@
 // the config struct, the raw hipStream_t), status codes out; no torch types, no logic.  The GIL is
 // released around every call.  gym_os2r_amd.sim uses it when OS2R_BINDING=pybind11 (default: ctypes).
 #include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
 
 #include <cstdint>
 
@@ -52,6 +53,14 @@ PYBIND11_MODULE(_os2r_py, m) {
   m.def("bench_enqueue", [](addr h, int n, addr st) {
     py::gil_scoped_release rel;
     return os2r_bench_steps(H(h), n, P(st), nullptr);
+  });
+  m.def("bench_steps_multi", [](std::vector<addr> hs, std::vector<addr> sts, int n) {
+    std::vector<Os2rSim*> sims; std::vector<void*> streams;
+    for (addr h : hs) sims.push_back(H(h));
+    for (addr s : sts) streams.push_back(P(s));
+    if (sims.size() != streams.size()) return (int)OS2R_ERR_INVALID;
+    py::gil_scoped_release rel;
+    return os2r_bench_steps_multi(sims.data(), streams.data(), (int)sims.size(), n);
   });
   m.def("set_work_counters", [](addr h, addr buf) { return os2r_set_work_counters(H(h), (uint64_t*)P(buf)); });
   m.def("set_done_reasons", [](addr h, addr buf) { return os2r_set_done_reasons(H(h), (uint16_t*)P(buf)); });

@@ -206,6 +206,19 @@ class HipSim:
         callers that drive several handles on several streams -- shards of one batch advancing independently."""
         self._check(self._lib.os2r_bench_steps(self._h, int(nsteps), self._stream(), None), "os2r_bench_steps")
 
+    @staticmethod
+    def bench_enqueue_shards(sims, streams, nsteps: int):
+        """Enqueue nsteps random-action steps of every shard `sims[i]` on `streams[i]` (torch streams), round robin and
+        without waiting (include/os2r.h: os2r_bench_steps_multi): all the streams start together."""
+        lib = sims[0]._lib
+        if isinstance(lib, _PybindLib):
+            rc = lib.m.bench_steps_multi([lib._a(s._h) for s in sims], [int(st.cuda_stream) for st in streams], int(nsteps))
+        else:
+            hs = (C.c_void_p * len(sims))(*[s._h for s in sims])
+            sts = (C.c_void_p * len(sims))(*[C.c_void_p(st.cuda_stream) for st in streams])
+            rc = lib.os2r_bench_steps_multi(hs, sts, len(sims), int(nsteps))
+        sims[0]._check(rc, "os2r_bench_steps_multi")
+
     WORK_COUNTERS = ("wave_iterations", "scanned_bodies", "row_bodies", "body_sweeps", "sweeps", "lane_contacts",
                      "live_lane_sweeps", "full_sincos", "exact_solves", "lane_exact_solves")
 

@@ -276,6 +276,9 @@ int os2r_set_step_count(Os2rSim* sim, uint64_t value);
  * elapsed_ms == NULL: the launches are only enqueued (no events, no synchronisation) -- for a caller that drives
  * several handles on several streams (shards of one batch that advance independently) and times them itself.  */
 int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
+/* The same for `count` handles on `count` streams -- the shards of one batch --, enqueue only: step k of every shard is
+ * enqueued before step k + 1 of any (round robin), so that all the streams start together.                        */
+int os2r_bench_steps_multi(Os2rSim* const* sims, void* const* streams, int count, int nsteps);
 
 /* Work counters (measurement support, bench.py's roofline): while a buffer of OS2R_NUM_WORK_COUNTERS uint64 (device
  * memory, zeroed by the caller) is set, os2r_step launches the counting variant of the step kernel -- the same

@@ -496,7 +496,7 @@ def test_one_rccl_rank_runs_the_distributed_bracket_of_the_bench(tmp_path):
     import json
     import subprocess
     import sys
-    for extra in ([], ["--gather-obs"], ["--splits", "1"]):
+    for extra in ([], ["--gather-obs"], ["--splits", "4"]):
         env = dict(os.environ, MASTER_PORT="29541", MASTER_ADDR="127.0.0.1", OS2R_BENCH_FORCE_DIST="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--steps", "20", "--warmup", "5",
                "--preroll", "50", "--no-cpu-baseline", "--no-count"] + extra
@@ -504,7 +504,7 @@ def test_one_rccl_rank_runs_the_distributed_bracket_of_the_bench(tmp_path):
         assert r.returncode == 0, (extra, r.stderr[-2000:])
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert d["n_gpus"] == 1 and d["config"]["n_ranks_seen"] == 1 and d["config"]["total_envs"] == 65536
-        assert d["config"]["splits"] == (4 if not extra else 1)       # the default: four shards; the gather experiment and --splits 1: one
+        assert d["config"]["splits"] == (4 if "--splits" in extra else 1)
         assert d["value"] == pytest.approx(65536 * 20 / (d["ms_per_step"] * 1e-3 * 20), rel=1e-6)
         assert 0 < d["roofline"]["kernel_ms_per_launch"] and d["roofline"]["kernel_ms_per_launch"] <= d["ms_per_step"] * 1.5
 

@@ -11,7 +11,7 @@ show() { python - "$1" <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1])); rv = d.get("roofline_valu", {}); cb = d.get("cpu_baseline", {})
-    print(sys.argv[1].split("/")[-1], round(d["value"] / 1e6, 1), "M/s", round(d["ms_per_step"] * 1e3, 2), "us/step kernel", round(d["roofline"]["kernel_ms_per_launch"] * 1e3, 2), "valu frac", rv.get("frac"), "useful", rv.get("frac_useful"), "flops/env-step", rv.get("issued_lane_flops_per_env_step"), "cpu", cb.get("value"))
+    print(sys.argv[1].split("/")[-1], round(d["value"] / 1e6, 1), "M/s", round(d["ms_per_step"] * 1e3, 2), "us/step kernel", round(d["roofline"]["kernel_ms_per_launch"] * 1e3, 2), "valu frac", rv.get("frac"), "useful", rv.get("frac_useful"), "flops/env-step", rv.get("issued_lane_flops_per_env_step"), "cpu", cb.get("value"), "| sweeps", round(rv.get("activity", {}).get("phase2_sweeps_per_wave_iteration", 0), 2), "solves", round(rv.get("activity", {}).get("exact_solves_per_wave_iteration", 0), 2), "envs/solve", round(rv.get("activity", {}).get("envs_per_exact_solve", 0), 2))
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
@@ -45,3 +45,6 @@ timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ
 cd "$ROOT"; python tools/flop_model.py fit "$OUT/flopmodel" "$OUT/flop_model" | tail -12
 rm -rf "$OUT/flopmodel/pmc_C4"   # (large; the fit is what is kept)
 sed -n 1,30p "$OUT/r03_step_kernel_f64_C4.md"
+# the raw rocprofv3 output is large (8560 dispatches per pass) and is not kept: the summaries above are
+rm -rf gpurun_out/prof_r03
+du -sh gpurun_out
