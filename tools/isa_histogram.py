@@ -66,7 +66,7 @@ def disassemble(path, needle, counting=False):
             funcs = [ln.split() for ln in syms.splitlines() if " FUNC " in ln]
             names = [x[7] for x in funcs]
             for x, dn in zip(funcs, demangle(names)):
-                is_counting = dn.rstrip().endswith(", true>(os2r::StepArgs<double>)") or ", true>(os2r::StepArgs<float>)" in dn
+                is_counting = re.search(r", true(, \d+)?>\(os2r::StepArgs<", dn) is not None   # the COUNT template argument
                 if needle in dn and is_counting == counting:
                     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f"--disassemble-symbols={x[7]}", f.name],
                                          capture_output=True, text=True).stdout

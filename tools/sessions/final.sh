@@ -21,11 +21,11 @@ PY
 timeout -k 10 300 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; show "$OUT/bench_default.json"
 B="timeout -k 10 200 python bench.py --no-cpu-baseline"
 $B --steps 20 --warmup 5 > "$OUT/bench_20_5.json" 2>/dev/null; show "$OUT/bench_20_5.json"
-$B --splits 1 > "$OUT/bench_splits1.json" 2>/dev/null; show "$OUT/bench_splits1.json"
+$B --splits 4 > "$OUT/bench_splits4.json" 2>/dev/null; show "$OUT/bench_splits4.json"
 $B --splits 2 > "$OUT/bench_splits2.json" 2>/dev/null; show "$OUT/bench_splits2.json"
 $B --pgs-exact 0 --pgs-iters 20 > "$OUT/bench_sweeps_only.json" 2>/dev/null; show "$OUT/bench_sweeps_only.json"
-$B --pgs-exact 0 --pgs-iters 20 --splits 1 > "$OUT/bench_sweeps_only_splits1.json" 2>/dev/null; show "$OUT/bench_sweeps_only_splits1.json"
-$B --pgs-tol 1e-3 --splits 1 > "$OUT/bench_floor.json" 2>/dev/null; show "$OUT/bench_floor.json"
+$B --pgs-exact 0 --pgs-iters 20 --steps 20 --warmup 5 > "$OUT/bench_sweeps_only_20_5.json" 2>/dev/null; show "$OUT/bench_sweeps_only_20_5.json"
+$B --pgs-tol 1e-3 > "$OUT/bench_floor.json" 2>/dev/null; show "$OUT/bench_floor.json"
 for w in C2 C3 V1; do $B --workload $w > "$OUT/bench_$w.json" 2>/dev/null; show "$OUT/bench_$w.json"; done
 $B --runtime-model > "$OUT/bench_rt.json" 2>/dev/null; show "$OUT/bench_rt.json"
 $B --envs-per-gpu 131072 --steps 500 > "$OUT/bench_128k.json" 2>/dev/null; show "$OUT/bench_128k.json"
@@ -37,7 +37,7 @@ OS2R_CLOCK_JSON="$OUT/clock.json" timeout -k 10 200 python tools/dbg/stamps.py C
 rm -rf gpurun_out/prof_r03
 bash tools/profile.sh r03 --no-count > "$OUT/profile.log" 2>&1; echo "profile rc=$?"
 bash tools/profile_issue.sh r03 --no-count > "$OUT/profile_issue.log" 2>&1; echo "profile_issue rc=$?"
-OS2R_TIMED_STEPS=4000 python tools/summarize_profile.py gpurun_out/prof_r03 "$OUT/r03_step_kernel_f64_C4" step_kernel "$OUT/traffic.json" "$OUT/clock.json" > /dev/null
+OS2R_TIMED_STEPS=1000 python tools/summarize_profile.py gpurun_out/prof_r03 "$OUT/r03_step_kernel_f64_C4" step_kernel "$OUT/traffic.json" "$OUT/clock.json" > /dev/null
 python tools/issue_breakdown.py "$OUT/r03_step_kernel_f64_C4.json" "$OUT/r03_issue_breakdown" > /dev/null 2>&1; echo "issue rc=$?"
 timeout -k 10 300 python tools/flop_model.py counts --workload C4 --steps 1200 --out "$OUT/flopmodel/counts_C4.json"; echo "counts rc=$?"
 cd /tmp
