@@ -21,6 +21,41 @@ from gym_os2r_amd import randomizers
 from gym_os2r_amd.common import make_env_from_id
 
 
+def pipelined(args):
+    """A small policy network on shard A while the physics of shard B runs: every shard has its own handle and stream,
+    `step_async(a, split=i)` enqueues its env-step and returns, `step_wait(split=i)` hands back its tensors ordered behind
+    that launch on the caller's stream.  The results are those of the single batch (the RNG is keyed by the global index)."""
+    from gym_os2r_amd.common import make_mp_envs
+    vec = make_mp_envs(args.env_id, args.envs, 42, randomizers.monopod.MonopodEnvRandomizer, num_splits=args.splits,
+                       task_mode=args.task_mode, max_episode_steps=args.max_episode_steps)
+    obs_all = vec.reset()
+    dev, dt = obs_all.device, obs_all.dtype
+    D = obs_all.shape[1]
+    torch.manual_seed(0)
+    policy = torch.nn.Sequential(torch.nn.Linear(D, 64), torch.nn.Tanh(), torch.nn.Linear(64, 2), torch.nn.Tanh()).to(dev, dt)
+    obs = [obs_all[sl] for sl in vec.split_slices]
+    ret = [torch.zeros(sl.stop - sl.start, dtype=dt, device=dev) for sl in vec.split_slices]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.no_grad():
+        for i in range(vec.num_splits):                       # prime the pipeline: every shard gets its first launch
+            vec.step_async(policy(obs[i]), split=i)
+        for _ in range(args.steps - 1):
+            for i in range(vec.num_splits):
+                o, r, d, info = vec.step_wait(split=i)        # shard i's results; the other shards' physics keep running
+                ret[i].add_(r)
+                vec.step_async(policy(o), split=i)            # its next actions, its next launch
+        for i in range(vec.num_splits):
+            o, r, d, info = vec.step_wait(split=i)
+            ret[i].add_(r)
+    torch.cuda.synchronize()
+    dt_s = time.time() - t0
+    total = float(torch.cat(ret).mean())
+    print(f"{vec.num_splits} shards, policy and physics pipelined: {args.envs} envs x {args.steps} steps in {dt_s:.2f} s = "
+          f"{args.envs * args.steps / dt_s / 1e6:.1f} M env-steps/s; mean return per env {total:.2f}")
+    vec.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--env-id", default="Monopod-balance-v1")
@@ -28,11 +63,17 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--max-episode-steps", type=int, default=500)
+    ap.add_argument("--splits", type=int, default=0,
+                    help="pipeline the rollout over that many shards of the batch (HipVecEnv num_splits): while the physics of one "
+                         "shard runs on its stream, the policy of the next shard is evaluated -- what step_async / step_wait of the "
+                         "reference's SubprocVecEnv are for (common/vec_env/subproc_vec_env.py:114-123)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one loop iteration (policy, env step, bookkeeping) in a HIP graph and replay it: for small "
                          "batches the loop is bound by launches, not by the physics")
     args = ap.parse_args()
 
+    if args.splits > 0:
+        return pipelined(args)
     make_env = functools.partial(make_env_from_id, env_id=args.env_id, num_envs=args.envs, task_mode=args.task_mode,
                                  max_episode_steps=args.max_episode_steps)
     env = randomizers.monopod.MonopodEnvRandomizer(env=make_env)
