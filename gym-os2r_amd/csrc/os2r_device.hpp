@@ -530,6 +530,14 @@ constexpr int kStamps = 26;   // 0..11 phases, 12..23 finer marks inside the dyn
 #define OS2R_STAMP(idx) do { } while (0)
 #endif
 
+// Static markers in the ISA (diagnostic builds with -DOS2R_ISA_MARKS only: tools/isa_histogram.py --marks): s_nop with a
+// distinctive count at the boundaries of the exact solve's passes, so that their instruction counts can be read off
+#ifdef OS2R_ISA_MARKS
+#define OS2R_ISA_MARK(n) asm volatile("s_nop " #n ::: "memory")
+#else
+#define OS2R_ISA_MARK(n) do { } while (0)
+#endif
+
 // sched_barrier mask: everything may cross except vector-memory instructions
 constexpr int kPinVmem = 0x1 | 0x2 | 0x4 | 0x8 | 0x80 | 0x100 | 0x200 | 0x400;
 
@@ -1284,8 +1292,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     group(pgs_iters - it, false);
   };
   // ---- exact finish (fp64; kExact* above).  The rows of phase 2 in sweep order: ----
-  // f(slot, nz, g, target, lambda&, lo, hi, upper, rd): row `slot` has the non-zeros g[0..nz], an impulse in [lo, hi]
-  // (upper == false: no upper bound) and the reciprocal rd of |g|^2 (0: row off)
+  // f(slot, nz, g, target, lambda&, lo, hi, upper): row `slot` has the non-zeros g[0..nz] and an impulse in [lo, hi]
+  // (upper == false: no upper bound)
   auto each_row = [&](auto first, auto&& f) {
     constexpr int kFirst = decltype(first)::value;
 #pragma unroll
@@ -1293,12 +1301,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
       const T lim = limfix[b];
-      f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(0), false, dn[b]);
-      f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true, dx[b]);
-      f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true, dy[b]);
+      f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(0), false);
+      f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true);
+      f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true);
     }
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true, idj[j]);
+    for (int j = 0; j < NQ; ++j) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true);
   };
   // One exact solve of the rows strictly inside their box, every other row held at its bound.  Returns whether a
   // bound cut the step short (that row then sits on its bound and the caller solves again with the smaller set).
@@ -1315,11 +1323,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int k = 0; k < NT; ++k) S[k] = T(0);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) h[k] = T(0);
+    OS2R_ISA_MARK(9);
     // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
     // A row that is free for none of the lanes at work here -- typically two or three of the 64 -- adds exact zeros to S
     // and h, has mu = 0 and keeps its impulse: the wave skips it in every pass (void for every lane, so a lane's result
     // does not depend on its company).
-    each_row(first, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper, T) {
+    each_row(first, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
       const bool fr = is_free(l, lo, hi, upper);
       if (__ballot(fr) == 0ull) return;
       // the row's weight as a number the optimiser cannot see through: it would turn the products below back into
@@ -1340,6 +1349,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         }
       }
     });
+    OS2R_ISA_MARK(10);
     T tr = T(0);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) tr += S[tri(i, i)];
@@ -1396,6 +1406,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
       for (int i = 0; i < NQ; ++i) { d[i] = z[i]; ds[i] = it == 0 ? z[i] : ds[i] + z[i]; }
     }
+    OS2R_ISA_MARK(11);
     // pass 2: impulses of the free rows from the residuals, mu = -(K w + g.ds) / eps, and whether the full step
     // would take a row out of its box
     const T ieps = -rcp_t(eps);
@@ -1409,7 +1420,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     auto mu_put = [&](int slot, T v) { if constexpr (kMuInLds) L(kMuSlot + slot) = v; else mu_reg[slot] = v; };
     auto mu_get = [&](int slot) -> T { if constexpr (kMuInLds) return L(kMuSlot + slot); else return mu_reg[slot]; };
     bool cut = false;
-    each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper, T) {
+    each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
       const bool fr = is_free(l, lo, hi, upper);
       if (__ballot(fr) == 0ull) return;
       const T f = opaque(fr ? ieps : T(0));
@@ -1426,12 +1437,13 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       const T full = l + m;
       cut = cut | (full < lo) | (upper ? (full > hi) : false);
     });
+    OS2R_ISA_MARK(12);
     // the largest feasible fraction of the step: the wave computes it when one of its lanes needs it, and only the lanes
     // whose full step leaves a box take it
     T alpha = T(1);
     if (__ballot(cut) != 0ull) {
       T a = T(1);
-      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         const T m = mu_get(slot);
         const bool up = m > T(0);
@@ -1442,12 +1454,13 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       });
       alpha = cut ? a : T(1);
     }
+    OS2R_ISA_MARK(13);
     // the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
     // that the cut step has taken to its bound (the room left is below kExactSnap of what it had) is set on it
 #pragma unroll
     for (int i = 0; i < NQ; ++i) y[i] = fma_t(alpha, d[i], y[i]);
     if (__ballot(cut) != 0ull) {
-      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         const T m = mu_get(slot);
         T nl = fma_t(alpha, m, l);
@@ -1460,7 +1473,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         l = nl;
       });
     } else {
-      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper, T) {
+      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         T nl = l + mu_get(slot);
         nl = fmax_t(nl, lo);
@@ -1468,6 +1481,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         l = nl;
       });
     }
+    OS2R_ISA_MARK(14);
     return cut;
   };
   // Phase 2 with the exact finish: kExactFirst sweeps, the last of them measured; from then on an environment that is

@@ -103,6 +103,10 @@ def main():
     ap.add_argument("kernel", nargs="?", default=DEFAULT_KERNEL)
     ap.add_argument("--loops", action="store_true")
     ap.add_argument("--min-loop", type=int, default=40, help="smallest loop body (instructions) worth listing")
+    ap.add_argument("--marks", action="store_true",
+                    help="for an object built with -DOS2R_ISA_MARKS: instructions between consecutive `s_nop 9..14` markers, i.e. per "
+                         "pass of the exact solve (pass 1, factorisation + proximal solves, pass 2, step length, apply), once per "
+                         "instantiated form of the solver")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     name, size, insts = disassemble(a.path, a.kernel)
@@ -130,6 +134,14 @@ def main():
                 continue
             seen.add((lo, hi))
             report(f"loop body at +0x{insts[lo][0] - insts[0][0]:x} .. +0x{insts[hi][0] - insts[0][0]:x}", insts[lo:hi + 1], out)
+    if a.marks:
+        names = {9: "pass 1 (S, h)", 10: "factorisation + proximal solves", 11: "pass 2 (impulses, cut test)", 12: "step length (cut steps only)",
+                 13: "apply (cut and full-step variants)"}
+        marks = [(i, int(o)) for i, (_, m, o) in enumerate(insts) if m == "s_nop" and o.strip().isdigit() and 9 <= int(o) <= 14]
+        for k in range(len(marks) - 1):
+            (i, m0), (j, m1) = marks[k], marks[k + 1]
+            if m1 == m0 + 1:
+                report(f"exact solve, {names.get(m0, m0)} [instantiation {1 + sum(1 for _, mm in marks[:k + 1] if mm == 9)}]", insts[i + 1:j], out)
     if a.json:
         json.dump(out, open(a.json, "w"), indent=1)
 
