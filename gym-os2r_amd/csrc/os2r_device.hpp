@@ -1323,6 +1323,16 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int k = 0; k < NT; ++k) S[k] = T(0);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) h[k] = T(0);
+    // The multipliers wait between the passes: in
+    // registers in the kernels built for the default solver settings, in free per-lane LDS slots (behind the factor's
+    // mirror) in the others, whose register file is full -- they also carry the sweeps-only solver and, for run-time
+    // models, rows for every body (scratch otherwise: 12-370 B per lane)
+    constexpr bool kMuInLds = !kStdExact;
+    constexpr int kMuSlot = NQ * (NQ + 1) / 2;
+    static_assert(kMuSlot + 3 * NB + NQ <= 8 * NQ, "per-lane LDS slots");
+    T mu_reg[kMuInLds ? 1 : 3 * NB + NQ];
+    auto mu_put = [&](int slot, T v) { if constexpr (kMuInLds) L(kMuSlot + slot) = v; else mu_reg[slot] = v; };
+    auto mu_get = [&](int slot) -> T { if constexpr (kMuInLds) return L(kMuSlot + slot); else return mu_reg[slot]; };
     OS2R_ISA_MARK(9);
     // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
     // A row that is free for none of the lanes at work here -- typically two or three of the 64 -- adds exact zeros to S
@@ -1410,19 +1420,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // pass 2: impulses of the free rows from the residuals, mu = -(K w + g.ds) / eps, and whether the full step
     // would take a row out of its box
     const T ieps = -rcp_t(eps);
-    // The multipliers wait between the passes: in registers in the kernels built for the default solver settings, in
-    // free per-lane LDS slots (behind the factor's mirror) in the others, whose register file is full -- they also
-    // carry the sweeps-only solver and, for run-time models, rows for every body (scratch otherwise: 12-370 B per lane)
-    constexpr bool kMuInLds = !kStdExact;
-    constexpr int kMuSlot = NQ * (NQ + 1) / 2;
-    static_assert(kMuSlot + 3 * NB + NQ <= 8 * NQ, "per-lane LDS slots");
-    T mu_reg[kMuInLds ? 1 : 3 * NB + NQ];
-    auto mu_put = [&](int slot, T v) { if constexpr (kMuInLds) L(kMuSlot + slot) = v; else mu_reg[slot] = v; };
-    auto mu_get = [&](int slot) -> T { if constexpr (kMuInLds) return L(kMuSlot + slot); else return mu_reg[slot]; };
     bool cut = false;
     each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
       const bool fr = is_free(l, lo, hi, upper);
-      if (__ballot(fr) == 0ull) return;
+      if (__ballot(fr) == 0ull) { mu_put(slot, T(0)); return; }   // (the full step below adds it without asking)
       const T f = opaque(fr ? ieps : T(0));
       T w = -target;
 #pragma unroll
@@ -1473,8 +1474,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         l = nl;
       });
     } else {
+      // (no test: a row that is not free has the multiplier 0 and sits inside its box)
       each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
-        if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         T nl = l + mu_get(slot);
         nl = fmax_t(nl, lo);
         if (upper) nl = fmin_t(nl, hi);

@@ -40,12 +40,14 @@ def main():
     sim.bench_steps(int(sys.argv[2]) if len(sys.argv) > 2 else 50)
     assert lib.os2r_debug_set_stamp_buffer(sim._h, C.c_void_p(buf.data_ptr())) == 0
     acc = np.zeros(NS)
+    totals = []
     for _ in range(20):
         sim.step(None, want_terminal=False)
         torch.cuda.synchronize()
         per_wave = buf.cpu().numpy().reshape(nwg, NS)
         acc += per_wave.mean(axis=0)
         tot_w = per_wave[:, :24].sum(axis=1)
+        totals.append(tot_w.copy())
         spread = (tot_w.min(), tot_w.mean(), tot_w.max(), tot_w.std(), np.percentile(tot_w, 50), np.percentile(tot_w, 99))
     acc /= 20
     ghz = float(np.median(per_wave[:, 24] / np.maximum(per_wave[:, 25], 1)) * 0.1)
@@ -62,6 +64,26 @@ def main():
     print(f"per-wave ticks of the last step: min {spread[0]:.0f} mean {spread[1]:.0f} max {spread[2]:.0f} (max/mean {spread[2] / spread[1]:.3f}; std {spread[3]:.0f}, median {spread[4]:.0f}, p99 {spread[5]:.0f})")
     for name, v in zip(PHASES, acc):
         print(f"  {name:42s} {v / cfg.substeps:9.0f} ticks/iter  {100 * v / tot:5.1f} %")
+    tail_report(per_wave, totals, cfg.substeps)
+
+
+def tail_report(per_wave, totals, substeps):
+    """What the slowest waves of the last stamped launch did differently, and whether a slow wave stays slow."""
+    tot = per_wave[:, :24].sum(axis=1)
+    order = np.argsort(-tot)
+    mean = per_wave[:, :24].mean(axis=0)
+    k = max(len(tot) // 100, 1)
+    top = per_wave[order[:k], :24].mean(axis=0)
+    print(f"slowest {k} waves of the last launch against the mean wave ({top.sum():.0f} vs {mean.sum():.0f} ticks): the difference by phase")
+    diff = top - mean
+    for i in np.argsort(-diff)[:8]:
+        print(f"  {PHASES[i]:42s} {diff[i] / substeps:+9.0f} ticks/iter  {100 * diff[i] / diff.sum():5.1f} % of the gap   (mean {mean[i] / substeps:.0f})")
+    T = np.stack(totals)                      # [launch, wave]
+    c = np.corrcoef(T[-2], T[-1])[0, 1]
+    c10 = np.corrcoef(T[-11], T[-1])[0, 1] if len(T) > 10 else float('nan')
+    print(f"correlation of a wave's ticks between consecutive launches {c:.2f}, ten launches apart {c10:.2f}")
+    avg = T.mean(axis=0)
+    print(f"mean over the 20 launches per wave: max/mean {avg.max() / avg.mean():.3f} (a launch: {np.mean(T.max(axis=1) / T.mean(axis=1)):.3f})")
 
 
 if __name__ == "__main__":
