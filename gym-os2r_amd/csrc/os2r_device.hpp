@@ -57,6 +57,11 @@ constexpr int kPgsGroup = 4;
 #endif
 constexpr int kExactFirst = OS2R_EXACT_FIRST, kExactProx = 3;
 constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;
+// An inconsistent free set (more sticking rows than the dof they act on) leaves a residual on its rows and multipliers
+// that move by the same amount round after round: from an environment's second solve of an iteration on, a solve that
+// is not cut and leaves more than kExactIncons of the squared residual it found steps on along its multipliers -- past
+// the full step -- to the first bound, and counts as cut.
+constexpr double kExactIncons = 1e-4, kExactNoBound = 1e300;
 
 // Work done by one wave in one physics iteration, for the counting kernel variants (wave-uniform values).
 struct WorkCounts {
@@ -1311,7 +1316,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // One exact solve of the rows strictly inside their box, every other row held at its bound.  Returns whether a
   // bound cut the step short (that row then sits on its bound and the caller solves again with the smaller set).
   // Runs under the mask of the lanes that need it; nothing in it looks at another lane.
-  auto exact_solve = [&](auto first) -> bool {
+  auto exact_solve = [&](auto first, bool test_consistency) -> bool {
     constexpr int NT = NQ * (NQ + 1) / 2;
     auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };   // j <= i
     // Branch-free on purpose (bitwise logic on the predicates, selects, min / max): written with && / || and
@@ -1421,29 +1426,45 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // would take a row out of its box
     const T ieps = -rcp_t(eps);
     bool cut = false;
-    each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
-      const bool fr = is_free(l, lo, hi, upper);
-      if (__ballot(fr) == 0ull) { mu_put(slot, T(0)); return; }   // (the full step below adds it without asking)
-      const T f = opaque(fr ? ieps : T(0));
-      T w = -target;
+    // (the variant that also measures the residuals before and after the step runs when a lane of the wave asks for it)
+    T found = T(0), left = T(0);
+    auto pass2 = [&](auto measure_) {
+      each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
+        const bool fr = is_free(l, lo, hi, upper);
+        if (__ballot(fr) == 0ull) { mu_put(slot, T(0)); return; }   // (the full step below adds it without asking)
+        const T f = opaque(fr ? ieps : T(0));
+        T w = -target;
 #pragma unroll
-      for (int k = 0; k < NQ; ++k)
-        if (k <= nz) w = fma_t(g[k], y[k], w);
-      T r = T(kExactProx) * w;
+        for (int k = 0; k < NQ; ++k)
+          if (k <= nz) w = fma_t(g[k], y[k], w);
+        T r = T(kExactProx) * w;
 #pragma unroll
-      for (int k = 0; k < NQ; ++k)
-        if (k <= nz) r = fma_t(g[k], ds[k], r);
-      const T m = opaque(r * f);
-      mu_put(slot, m);
-      const T full = l + m;
-      cut = cut | (full < lo) | (upper ? (full > hi) : false);
-    });
+        for (int k = 0; k < NQ; ++k)
+          if (k <= nz) r = fma_t(g[k], ds[k], r);
+        const T m = opaque(r * f);
+        mu_put(slot, m);
+        const T full = l + m;
+        cut = cut | (full < lo) | (upper ? (full > hi) : false);
+        if constexpr (decltype(measure_)::value) {
+          T wl = w;
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            if (k <= nz) wl = fma_t(g[k], d[k], wl);
+          const T wf = opaque(fr ? w : T(0)), wlf = opaque(fr ? wl : T(0));
+          found = fma_t(wf, wf, found);
+          left = fma_t(wlf, wlf, left);
+        }
+      });
+    };
+    if (__ballot(test_consistency) != 0ull) pass2(std::true_type{});
+    else pass2(std::false_type{});
+    const bool incons = test_consistency & !cut & (left > T(kExactIncons) * found);
     OS2R_ISA_MARK(12);
     // the largest feasible fraction of the step: the wave computes it when one of its lanes needs it, and only the lanes
     // whose full step leaves a box take it
     T alpha = T(1);
-    if (__ballot(cut) != 0ull) {
-      T a = T(1);
+    if (__ballot(cut | incons) != 0ull) {
+      T a = incons ? T(kExactNoBound) : T(1);
       each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
         const T m = mu_get(slot);
@@ -1453,6 +1474,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         const T lim = opaque(room * rcp_t(bounded ? m : T(1)));   // same sign as m, so lim >= 0
         a = (bounded & (lim < a)) ? lim : a;
       });
+      cut = cut | (incons & (a < T(kExactNoBound)));   // the long step ends on a bound: the same as a cut
       alpha = cut ? a : T(1);
     }
     OS2R_ISA_MARK(13);
@@ -1514,7 +1536,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       bool again = false;
       OS2R_STAMP(8);
       if (do_solve) {
-        again = exact_solve(first);
+        again = exact_solve(first, solves > 0);
         ++solves;
         again = again && solves < pgs_exact;
       }

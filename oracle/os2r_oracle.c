@@ -652,6 +652,14 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX 3
 #define ORC_EXACT_SNAP 1e-12
+/* A free set can be INCONSISTENT: more sticking rows than the degrees of freedom they act on (four or five of them on
+ * the three dof of `monopod-fixed`, two sticking contacts in five dof).  The solve then ends at the least-squares point
+ * with a residual left on the free rows, and the multipliers do not converge: every round moves them on by the same
+ * amount until, tens of rounds later, one of them reaches its bound.  From an environment's second solve of a physics
+ * iteration on, a solve that is not cut therefore measures what it leaves on its free rows; if that is more than
+ * ORC_EXACT_INCONS of what it found (squared norms), it goes on in the direction of its multipliers -- past the full
+ * step -- to the first bound it meets, sets that row on it and solves again, as after a cut. */
+#define ORC_EXACT_INCONS 1e-4
 
 static void chol_lower(int n, const double* a, double* l) {   /* a = l l^T, row-major n x n */
   for (int i = 0; i < n * n; ++i) l[i] = 0.0;
@@ -674,7 +682,7 @@ static void row_box(const Row* rows, const Row* R, int fixed_box, double* lo, do
 }
 
 /* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
-static int exact_step(int n, Row* rows, int nr, const double* lc, double* v) {
+static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int test_consistency) {
   double g[3 * OS2R_MAX_DOF + OS2R_MAX_DOF][OS2R_MAX_DOF], w[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   int fr[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   double S[OS2R_MAX_DOF][OS2R_MAX_DOF] = {{0}}, h[OS2R_MAX_DOF] = {0};
@@ -716,18 +724,23 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v) {
   /* impulses of the free rows; does the full step take one of them out of its box? */
   double mu[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   int cut = 0;
+  double found = 0.0, left = 0.0;   /* squared residuals of the free rows before and after the step */
   for (int r = 0; r < nr; ++r) {
     if (!fr[r]) continue;
     double s = ORC_EXACT_PROX * w[r];
     for (int k = 0; k < n; ++k) s += g[r][k] * ds[k];
     mu[r] = -s / eps;
+    double wl = w[r];
+    for (int k = 0; k < n; ++k) wl += g[r][k] * d[k];
+    found += w[r] * w[r]; left += wl * wl;
     double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
     const double full = rows[r].lambda + mu[r];
     if (full < lo || full > hi) cut = 1;
   }
-  /* if so, the largest feasible fraction of the step */
-  double alpha = 1.0;
-  if (cut)
+  /* if so, the largest feasible fraction of the step; an inconsistent free set: the step to the first bound, however long */
+  const int on = test_consistency && !cut && left > ORC_EXACT_INCONS * found;
+  double alpha = on ? INFINITY : 1.0;
+  if (cut || on)
     for (int r = 0; r < nr; ++r) {
       if (!fr[r] || mu[r] == 0.0) continue;
       double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
@@ -735,6 +748,7 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v) {
       const double lim = ((mu[r] > 0.0 ? hi : lo) - rows[r].lambda) / mu[r];
       if (lim < alpha) alpha = lim;
     }
+  if (on) { if (isfinite(alpha)) cut = 1; else alpha = 1.0; }
   /* the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
    * that the cut step has taken to its bound (the room left is below ORC_EXACT_SNAP of what it had) is set on it */
   for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k <= i; ++k) s += lc[i * n + k] * d[k]; v[i] += alpha * s; }
@@ -781,7 +795,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
        * the step short) precede every sweep until the budget `exact` is spent */
       if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST && solves < exact) {
         int blocked = 1;
-        while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v); ++solves; }
+        while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; }
         tl_last_solves = solves;
       }
       if (phase == 1) tl_last_sweeps = it + 1;

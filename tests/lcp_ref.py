@@ -105,11 +105,13 @@ def pgs_two_phase(p, normal_iters=3, iters=20, tol=1e-24, group=4):
     return v, lam, box, ran
 
 
-def pgs_exact_finish(p, normal_iters=3, iters=12, tol=1e-24, exact=12, first=4, eps_rel=1e-6, prox=3, snap=1e-12):
+def pgs_exact_finish(p, normal_iters=3, iters=12, tol=1e-24, exact=12, first=4, eps_rel=1e-6, prox=3, snap=1e-12, incons=1e-4):
     """The specification's solver with the exact finish, restated on the
     exported rows: phase 1 as in pgs_two_phase; phase 2 = `first` sweeps, then -- while the last sweep moved more than
     `tol` -- exact solves of the free rows (repeated while a bound cuts the step short, `exact` at most) each followed
-    by one sweep; `iters` bounds the sweeps.  -> (v, lam, box, sweeps of phase 2, exact solves)"""
+    by one sweep; `iters` bounds the sweeps.  From the second solve of the call on, a solve that is not cut and leaves
+    more than `incons` of the squared residual it found on its free rows (an inconsistent free set) goes on along its
+    multipliers to the first bound and counts as cut.  -> (v, lam, box, sweeps of phase 2, exact solves)"""
     J, minv, t, kind, nrow = p["J"], p["minv"], p["target"], p["kind"], p["normal_row"]
     nr, n = J.shape
     Lc = np.linalg.cholesky(minv)
@@ -165,11 +167,16 @@ def pgs_exact_finish(p, normal_iters=3, iters=12, tol=1e-24, exact=12, first=4, 
                 mu = -(prox * w + G[F] @ ds) / eps
                 full = lam[F] + mu
                 blocked = bool(((full < lo[F]) | (full > hi[F])).any())      # the full step leaves a box: cut it
+                left = w + G[F] @ dk
+                on = solves > 1 and not blocked and left @ left > incons * (w @ w)
                 alpha = 1.0
-                if blocked:
+                if blocked or on:
                     with np.errstate(divide="ignore", invalid="ignore"):
                         lim = np.where(mu > 0, (hi[F] - lam[F]) / mu, np.where(mu < 0, (lo[F] - lam[F]) / mu, np.inf))
-                    alpha = min(1.0, lim.min())
+                    alpha = min(1.0, lim.min()) if blocked else lim.min()
+                    if on:                           # inconsistent free set: on to the first bound, however far
+                        blocked = bool(np.isfinite(alpha))
+                        alpha = alpha if blocked else 1.0
                 y += alpha * dk
                 idx = np.nonzero(F)[0]
                 for j, m in zip(idx, mu):
