@@ -123,6 +123,36 @@ def _hard_problems(oracle, regime):
                     for _ in range(rng.integers(0, 10)):
                         qq, vv = oracle.substep(cfg, qq, vv, a, *par)
                     out.append((qq, vv, a, par))
+    elif regime == "fixed":
+        # task mode `fixed` (three dof): a sticking contact plus sticking joints are more rows than dof -- the inconsistent
+        # free sets of DESIGN.md 3.2.  Snapshots as above, plus every (environment, iteration) of three env-steps that took
+        # the default solve three exact solves or more (a few in a thousand).
+        n = 1024
+        cfg, task, model = make_config("fixed", "BalancingV2", True, num_envs=n, reset_mode=abi.RESET_RANDOM, randomize_params=True,
+                                       max_episode_steps=100000, seed=42, contact=True)
+        o = oracle.OracleSim(cfg, threads=8)
+        o.solver_counts()
+        for k in range(700):
+            q, qd = o.get_state()
+            P = [o.get_params(f) for f in range(5)]
+            o.step(None)
+            if k >= 300 and k % 100 == 0:
+                for e in range(0, n, 4):
+                    a = rng.uniform(-1, 1, 2) * 2.5
+                    par = (P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e])
+                    qq, vv = q[:, e].copy(), qd[:, e].copy()
+                    for _ in range(rng.integers(0, 10)):
+                        qq, vv = oracle.substep(cfg, qq, vv, a, *par)
+                    out.append((qq, vv, a, par))
+            if k >= 697:
+                sw, so = o.solver_counts()
+                held = o.get_action_history(0) * 2.5
+                for it, e in zip(*np.nonzero(so >= 3)):
+                    par = (P[0][:, e], P[1][:, e], P[2][:, e], P[3][:, e], P[4][0, e])
+                    qq, vv = q[:, e].copy(), qd[:, e].copy()
+                    for _ in range(int(it)):
+                        qq, vv = oracle.substep(cfg, qq, vv, held[:, e], *par)
+                    out.append((qq, vv, held[:, e].copy(), par))
     else:
         n = 64
         cfg, task, model = make_config("free_hip", "BalancingV2", True, num_envs=n, contact=True, auto_reset=False, seed=42,
@@ -158,14 +188,14 @@ def _certified_reference(oracle, cfg, state, p, enumerate_small):
     cands = [(lcp_ref.kkt_residual(A, c, lo, hi, pc["lambda"]), pc["v"], False)]
     v_t, lam_t, *_ = lcp_ref.pgs_exact_finish(p, cfg.pgs_normal_iters, 300, 0.0, exact=100)
     cands.append((lcp_ref.kkt_residual(A, c, lo, hi, lam_t), v_t, False))
-    if enumerate_small and p["nr"] == 8:                       # one contact: 4374 active sets at most
+    if enumerate_small and p["nr"] == 3 + cfg.model.nq:         # one contact: 4374 active sets at most
         lam_x, r_x = lcp_ref.enumerate_exact(A, c, lo, hi)
         cands.append((r_x, lcp_ref.velocity(pc, lam_x), True))
     r, v, enum = min(cands, key=lambda t: t[0])
     return v, r, enum, cands
 
 
-@pytest.mark.parametrize("regime", ["bench", "balancing"])
+@pytest.mark.parametrize("regime", ["bench", "balancing", "fixed"])
 def test_boxed_lcp_solution_against_the_exact_solution(oracle, regime):
     """(a) numpy restatements reproduce the oracle's velocity: the exact finish (the default) and the sweeps-only solver
     of rounds 1-2; (b) an exact solution with a certificate exists for every problem (optimality residual <= 1e-9), and
@@ -179,7 +209,7 @@ def test_boxed_lcp_solution_against_the_exact_solution(oracle, regime):
     err_spec, err_legacy, n_enum, resid, solves = [], [], 0, [], []
     for e, st in enumerate(states):
         p = oracle.contact_problem(cfg, st[0], st[1], st[2], *st[3])
-        if p["nr"] <= 5:
+        if p["nr"] <= cfg.model.nq:
             continue
         scale = max(1.0, np.abs(p["v"]).max())
         v_np, lam_np, box_np, ran, ns = lcp_ref.pgs_exact_finish(p, cfg.pgs_normal_iters, cfg.pgs_iters, cfg.pgs_tol, exact=cfg.pgs_exact)
@@ -190,7 +220,7 @@ def test_boxed_lcp_solution_against_the_exact_solution(oracle, regime):
         np.testing.assert_allclose(v_l, pl["v"], rtol=0, atol=1e-11 * scale)    # (a) sweeps only
         v_x, r_x, enum, cands = _certified_reference(oracle, cfg, st, p, n_enum < 40)
         assert r_x < 1e-9, (e, [c[0] for c in cands])                          # (b)
-        if p["nr"] == 8 and n_enum < 40:
+        if p["nr"] == 3 + cfg.model.nq and n_enum < 40:
             n_enum += 1
             for r_c, v_c, _ in cands:                                           # certified candidates agree with the enumeration
                 if r_c < 1e-10:
@@ -206,6 +236,10 @@ def test_boxed_lcp_solution_against_the_exact_solution(oracle, regime):
           f"sweeps-only 3 + 20: p50 {q_(err_legacy, 50):.1e} p90 {q_(err_legacy, 90):.1e} p99 {q_(err_legacy, 99):.1e} max {err_legacy.max():.1e}")
     assert n_enum >= 30 and len(resid) >= 250
     assert q_(err_spec, 99) <= 1e-9 and err_spec.max() <= 1e-6                  # (c)
+    if regime == "fixed":
+        # inconsistent free sets leave by a step to the first bound: no problem needs the cap (12 solves; without that
+        # step a tenth of these problems took 8 to 12 and the multipliers crept to their bound round by round)
+        assert max(solves) <= 10 and sum(s_ >= 3 for s_ in solves) >= 10
 
 
 def test_stopping_rule_only_stops_converged_environments(oracle):
