@@ -170,8 +170,10 @@ typedef struct Os2rConfig {
   int32_t pgs_exact;       /* exact finish of the boxed LCP: an environment that   */
                            /*   has not converged after the first 4 sweeps of phase 2 solves its    */
                            /*   free rows exactly (a 5x5 system in the whitened velocities), with  */
-                           /*   active-set pivots, at most this many solves per substep; a checked */
-                           /*   sweep follows each unblocked solve.  0: sweeps only, checked every */
+                           /*   active-set pivots (a step cut at a bound; an inconsistent free set */
+                           /*   left by a step to the first bound), at most this many solves per   */
+                           /*   substep; a checked sweep follows each unblocked solve.             */
+                           /*   0: sweeps only, checked every                                      */
                            /*   4th (the round-1/2 solver).  Ignored with pgs_normal_iters == 0;   */
                            /*   needs dtype OS2R_F64.                                              */
   int32_t reserved0_;
