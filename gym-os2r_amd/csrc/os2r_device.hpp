@@ -609,7 +609,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T (&sn)[MD::NQ], T (&cs)[MD::NQ], bool first_iteration,
                                         T tau_hip, T tau_knee, T dt, T erp,
                                         T max_erv, T margin, int pgs_iters, int pgs_normal_iters, int pgs_exact, T pgs_tol, T* __restrict__ lds,
-                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst, WorkCounts& wc
+                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst, WorkCounts& wc, unsigned& hint
 #ifdef OS2R_STAMPS
                                         , unsigned long long (&stamps)[kStamps], unsigned long long& stamp_prev
 #endif
@@ -1517,6 +1517,33 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     if (nfirst > 0) { moved = T(0); sweep(std::false_type{}, first, std::true_type{}); }
     int sweeps = nfirst, solves = 0;
     bool live = nfirst > 0 && moved > tol_v && sweeps < pgs_iters;
+    // Active-set hints between the iterations of an env-step (a contact that slides does so for many iterations, and the
+    // sweeps approach the bound of its tangential impulse from inside without reaching it: the first solve of every
+    // iteration would take the row for sticking, be cut and have to be repeated): the tangential rows that ended the last
+    // iteration on a bound -- two bits per row, slot 2 * body + (0: x, 1: y), bit 0 lower, bit 1 upper -- and that the
+    // sweeps have left strictly inside are put on that bound before the first solve.  A wrong hint costs a round, no more:
+    // the re-test sweep releases the row.
+    if (__ballot(live && hint != 0u) != 0ull) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!((CMASK >> b) & 1u)) continue;
+        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+        const T lim = limfix[b];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          T& l = t == 0 ? lx[b] : ly[b];
+          const unsigned side = (hint >> (2 * (2 * b + t))) & 3u;
+          const bool ap = live & (side != 0u) & (l > -lim) & (l < lim) & ((t == 0 ? dx[b] : dy[b]) > T(0));   // (a contact that is not active has lim = 0)
+          if (__ballot(ap) == 0ull) continue;
+          const T nl = side == 2u ? lim : -lim;
+          const T dl = opaque(ap ? nl - l : T(0));
+          l = ap ? nl : l;
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            if (k <= b) y[k] = fma_t(Gr[b][1 + t][k], dl, y[k]);
+        }
+      }
+    }
     if constexpr (COUNT) {
       unsigned nb = 0;
 #pragma unroll
@@ -1559,6 +1586,24 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         live = moved > tol_v && sweeps < pgs_iters;
       }
     }
+    // what the next iteration is told: an environment that had to solve remembers its tangential rows on a bound
+    unsigned hn = 0u;
+    if (__ballot(solves > 0) != 0ull) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!((CMASK >> b) & 1u)) continue;
+        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+        const T lim = limfix[b];
+        const bool has = lim > T(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const T l = t == 0 ? lx[b] : ly[b];
+          const unsigned bits = (l <= -lim) ? 1u : ((l >= lim) ? 2u : 0u);
+          hn |= ((has & ((t == 0 ? dx[b] : dy[b]) > T(0))) ? bits : 0u) << (2 * (2 * b + t));
+        }
+      }
+    }
+    hint = solves > 0 ? hn : 0u;
   };
   int first_act = NB;
   bool is_suffix = true;

@@ -771,7 +771,22 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
 /* diagnostics: phase-2 sweeps and exact solves of the calling thread's last solve (orc_get_solver_counts) */
 static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 
-static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, int exact, const double* minv, double* v) {
+/* Active-set hints between the physics iterations of one env-step.  A contact that slides does so for many iterations
+ * in a row, and Gauss-Seidel approaches the bound of its tangential impulse from inside without reaching it: the first
+ * solve of EVERY iteration takes the row for sticking, is cut at the bound and has to be repeated -- and the wave that
+ * holds such an environment is the slowest of its launch.  So an environment that had to solve remembers which
+ * tangential rows ended the iteration ON a bound, and on which side (two bits per row slot); in the next iteration, if it
+ * still needs a solve after the first sweeps, the remembered rows that the sweeps have left strictly inside are put on
+ * that bound (of THIS iteration's box) before it solves.  A wrong hint costs work, not accuracy: the re-test sweep
+ * releases the row and the environment solves again.
+ * slot of a tangential row: 2 * body + (0: x, 1: y);  bit 2 slot: on the lower bound, 2 slot + 1: on the upper bound.
+ * Zero at the start of every env-step; an environment that needed no solve forgets. */
+static int hint_slot(const Row* rows, int r) { return rows[r].kind == 1 ? 2 * rows[r].body + (r - rows[r].normal_row - 1) : -1; }
+static int g_hints = 1;   /* experiments and tests: 0 switches the hints off */
+void orc_set_experimental_hints(int on) { g_hints = on; }
+
+static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, int exact, const double* minv, double* v,
+                       uint32_t* hint) {
   int order[ORC_MAX_ROWS];
   for (int r = 0; r < nr; ++r) order[r] = r;
   if (g_row_order != 0)
@@ -794,6 +809,18 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
       if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST && solves < exact) {
+        if (solves == 0 && hint && *hint != 0u && g_hints)
+          for (int r = 0; r < nr; ++r) {
+            Row* R = &rows[r];
+            const int slot = hint_slot(rows, r);
+            if (slot < 0 || !(R->d > 0.0)) continue;
+            const unsigned side = (*hint >> (2 * slot)) & 3u;
+            double lo, hi; row_box(rows, R, 1, &lo, &hi);
+            if (side == 0u || !(R->lambda > lo && R->lambda < hi)) continue;
+            const double nl = side == 2u ? hi : lo, dl = nl - R->lambda;
+            R->lambda = nl;
+            for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
+          }
         int blocked = 1;
         while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; }
         tl_last_solves = solves;
@@ -821,27 +848,42 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST : (it + 1) % ORC_PGS_GROUP == 0) break;
       }
     }
+    if (phase == 1 && hint) {
+      uint32_t hnew = 0u;
+      if (solves > 0)
+        for (int r = 0; r < nr; ++r) {
+          const int slot = hint_slot(rows, r);
+          if (slot < 0 || !(rows[r].d > 0.0)) continue;
+          double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+          if (!(hi > 0.0)) continue;
+          if (rows[r].lambda <= lo) hnew |= 1u << (2 * slot);
+          else if (rows[r].lambda >= hi) hnew |= 2u << (2 * slot);
+        }
+      *hint = hnew;
+    }
   }
 }
 
-static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
+static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvParams* ep, double* q, double* qd, const double tau2[2],
+                          uint32_t* hint) {
   const int n = cfg->model.nq;
   double v[OS2R_MAX_DOF], minv[OS2R_MAX_DOF * OS2R_MAX_DOF];
   if (contact_model == ORC_CONTACT_CENTROID) {
     Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
     const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
-    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, cfg->pgs_exact, minv, v);
+    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, cfg->pgs_exact, minv, v, hint);
   } else {
     Row* rows = (Row*)malloc(sizeof(Row) * ORC_MAX_ROWS);
     const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
-    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, 0, minv, v);
+    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, 0, minv, v, NULL);
     free(rows);
   }
   for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += cfg->dt * v[i]; }
 }
 
 static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
-  substep_model(cfg, ORC_CONTACT_CENTROID, ep, q, qd, tau2);
+  uint32_t hint = 0u;   /* a single iteration: nothing to remember */
+  substep_model(cfg, ORC_CONTACT_CENTROID, ep, q, qd, tau2, &hint);
 }
 
 static void params_from(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
@@ -865,7 +907,8 @@ void orc_substep_model(const Os2rConfig* cfg, int contact_model, const double* m
                        const double* friction, const double* mu, double gravity_z, double* q, double* qd,
                        const double tau2[2]) {
   EnvParams ep; params_from(cfg, mass_scale, damping, friction, mu, gravity_z, &ep);
-  substep_model(cfg, contact_model, &ep, q, qd, tau2);
+  uint32_t hint = 0u;
+  substep_model(cfg, contact_model, &ep, q, qd, tau2, &hint);
 }
 
 /* The boxed LCP of one physics iteration, laid open for independent checks (tests/test_oracle_contact.py):
@@ -893,7 +936,7 @@ int orc_contact_problem(const Os2rConfig* cfg, int contact_model, const double* 
     for (int i = 0; i < 3; ++i) point[3 * r + i] = rows[r].point[i];
   }
   const int coupled = contact_model != ORC_CONTACT_CENTROID || cfg->pgs_normal_iters == 0;
-  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, coupled ? 0 : cfg->pgs_exact, minv, v);
+  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, coupled ? 0 : cfg->pgs_exact, minv, v, NULL);
   for (int r = 0; r < nr; ++r) {
     lambda[r] = rows[r].lambda;
     if (rows[r].kind == 0) box[r] = INFINITY;
@@ -1071,8 +1114,9 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
     double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
     EnvParams ep; load_params(s, e, &ep);
     for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
+    uint32_t hint = 0u;
     for (int k = 0; k < cfg->substeps; ++k) {                                                          /* gazebo_runtime.py:70-77 */
-      substep_model(cfg, s->contact_model, &ep, q, qd, tau);
+      substep_model(cfg, s->contact_model, &ep, q, qd, tau, &hint);
       if (s->solver_counts) {
         s->solver_counts[(size_t)k * s->N + e] = (int8_t)(tl_last_sweeps > 127 ? 127 : tl_last_sweeps);
         s->solver_counts[((size_t)cfg->substeps + k) * s->N + e] = (int8_t)(tl_last_solves > 127 ? 127 : tl_last_solves);
