@@ -1533,6 +1533,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         for (int t = 0; t < 2; ++t) {
           T& l = t == 0 ? lx[b] : ly[b];
           const unsigned side = (hint >> (2 * (2 * b + t))) & 3u;
+          if (__ballot(live & (side != 0u)) == 0ull) continue;   // (nearly every row: two or three lanes are live, with a hint or two each)
           const bool ap = live & (side != 0u) & (l > -lim) & (l < lim) & ((t == 0 ? dx[b] : dy[b]) > T(0));   // (a contact that is not active has lim = 0)
           if (__ballot(ap) == 0ull) continue;
           const T nl = side == 2u ? lim : -lim;
@@ -1599,7 +1600,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         for (int t = 0; t < 2; ++t) {
           const T l = t == 0 ? lx[b] : ly[b];
           const unsigned bits = (l <= -lim) ? 1u : ((l >= lim) ? 2u : 0u);
-          hn |= ((has & ((t == 0 ? dx[b] : dy[b]) > T(0))) ? bits : 0u) << (2 * (2 * b + t));
+          hn |= (has ? bits : 0u) << (2 * (2 * b + t));   // (a void row keeps the impulse 0, inside a box with lim > 0)
         }
       }
     }
