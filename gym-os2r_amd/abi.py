@@ -31,7 +31,7 @@ PARAM_MASS_SCALE, PARAM_DAMPING, PARAM_FRICTION, PARAM_MU, PARAM_GRAVITY = range
 DONE_BIT, TRUNCATED_BIT, NONFINITE_BIT = 1, 2, 4
 
 # solver defaults (config_struct): sweeps only / with the exact finish
-DEFAULT_PGS_ITERS, DEFAULT_PGS_ITERS_EXACT, DEFAULT_PGS_EXACT = 20, 15, 12
+DEFAULT_PGS_ITERS, DEFAULT_PGS_ITERS_EXACT, DEFAULT_PGS_EXACT = 20, 14, 12
 
 
 class Os2rModel(C.Structure):
@@ -218,7 +218,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
                   contact_margin: float = 1e-3, pgs_tol: Optional[float] = None,
                   pgs_exact: Optional[int] = None) -> Os2rConfig:
-    """Solver defaults: fp64 -- 3 normal sweeps, then at most `pgs_iters` = 15 sweeps over all
+    """Solver defaults: fp64 -- 3 normal sweeps, then at most `pgs_iters` = 14 sweeps over all
     rows with the exact finish (`pgs_exact` = 12 free-set solves at most per physics iteration); fp32 -- sweeps only
     (20, checked every 4th: the exact finish needs fp64's headroom for its regularised 5 x 5 solve).  Passing
     `pgs_exact=0, pgs_iters=20` selects the round-1/2 solver in fp64 too."""

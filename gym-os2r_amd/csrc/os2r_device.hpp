@@ -38,7 +38,7 @@ constexpr int kWave = 64;
 // the solver settings of the default configuration: kernels built for them have compile-time loop bounds (+2 %).
 // fp64: the exact finish with its lower sweep cap; fp32: sweeps only (kExact* below)
 // (kExact: the exact finish is on, with any positive cap on the solves -- the cap stays a run-time value)
-template <typename T> struct StdSolver { static constexpr int kIters = 15, kNormalIters = 3; static constexpr bool kExact = true; };
+template <typename T> struct StdSolver { static constexpr int kIters = 14, kNormalIters = 3; static constexpr bool kExact = true; };
 template <> struct StdSolver<float> { static constexpr int kIters = 20, kNormalIters = 3; static constexpr bool kExact = false; };
 template <typename T> __host__ __device__ inline bool is_std_solver(int iters, int normal_iters, int exact) {
   return iters == StdSolver<T>::kIters && normal_iters == StdSolver<T>::kNormalIters && (exact > 0) == StdSolver<T>::kExact;
@@ -53,7 +53,7 @@ constexpr int kPgsGroup = 4;
 // S = G_F^T G_F (NQ x NQ whatever the number of free rows), eps = kExactEps * trace S, kExactProx proximal iterations,
 // impulses from the residuals -- cuts the step at the first bound it meets, and re-tests every row with one measured sweep.
 #ifndef OS2R_EXACT_FIRST   // (overridden in timing experiments only: tools/sessions/r3_first_sweeps.sh)
-#define OS2R_EXACT_FIRST 7
+#define OS2R_EXACT_FIRST 6
 #endif
 constexpr int kExactFirst = OS2R_EXACT_FIRST, kExactProx = 3;
 constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;

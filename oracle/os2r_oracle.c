@@ -648,7 +648,7 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
  * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
  * row and measures what it moved.  At most `exact` solves per physics iteration; the sweep cap `iters` still holds. */
-#define ORC_EXACT_FIRST 7
+#define ORC_EXACT_FIRST 6
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX 3
 #define ORC_EXACT_SNAP 1e-12
