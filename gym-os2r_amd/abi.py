@@ -31,7 +31,17 @@ PARAM_MASS_SCALE, PARAM_DAMPING, PARAM_FRICTION, PARAM_MU, PARAM_GRAVITY = range
 DONE_BIT, TRUNCATED_BIT, NONFINITE_BIT = 1, 2, 4
 
 # solver defaults (config_struct): sweeps only / with the exact finish
-DEFAULT_PGS_ITERS, DEFAULT_PGS_ITERS_EXACT, DEFAULT_PGS_EXACT = 20, 14, 12
+DEFAULT_PGS_ITERS, DEFAULT_PGS_EXACT = 20, 12
+
+
+def default_pgs_iters_exact(nq: int) -> int:
+    """Sweep cap of the exact finish: the sweeps before the first check (six for the 5-dof robot, four for the smaller
+    ones: csrc/os2r_device.hpp exact_first) plus eight re-test sweeps.  The kernels built for these settings have
+    compile-time loop bounds."""
+    return (6 if int(nq) >= 5 else 4) + 8
+
+
+DEFAULT_PGS_ITERS_EXACT = default_pgs_iters_exact(5)
 
 
 class Os2rModel(C.Structure):
@@ -218,7 +228,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
                   contact_margin: float = 1e-3, pgs_tol: Optional[float] = None,
                   pgs_exact: Optional[int] = None) -> Os2rConfig:
-    """Solver defaults: fp64 -- 3 normal sweeps, then at most `pgs_iters` = 14 sweeps over all
+    """Solver defaults: fp64 -- 3 normal sweeps, then at most `pgs_iters` = 14 (12 below five dof) sweeps over all
     rows with the exact finish (`pgs_exact` = 12 free-set solves at most per physics iteration); fp32 -- sweeps only
     (20, checked every 4th: the exact finish needs fp64's headroom for its regularised 5 x 5 solve).  Passing
     `pgs_exact=0, pgs_iters=20` selects the round-1/2 solver in fp64 too."""
@@ -235,7 +245,7 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     if pgs_exact is None:
         pgs_exact = DEFAULT_PGS_EXACT if dtype == F64 and pgs_normal_iters > 0 else 0
     if pgs_iters is None:
-        pgs_iters = DEFAULT_PGS_ITERS_EXACT if pgs_exact > 0 else DEFAULT_PGS_ITERS
+        pgs_iters = default_pgs_iters_exact(int(model_struct(model).nq)) if pgs_exact > 0 else DEFAULT_PGS_ITERS
     c.pgs_iters = int(pgs_iters)
     c.pgs_exact = int(pgs_exact)
     c.pgs_normal_iters = int(pgs_normal_iters)

@@ -280,7 +280,7 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
   StepArgs<T> a = make_args<T>(s);
   a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
   const bool contact = s->cfg.contact != 0 && s->cmask != 0u;
-  const bool std_sweeps = is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact);
+  const bool std_sweeps = is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact, s->cfg.model.nq);
   hipFunction_t jit_fn = !s->jit ? nullptr
       : (std_sweeps && s->jit->fn[contact][s->dr][1]) ? s->jit->fn[contact][s->dr][1] : s->jit->fn[contact][s->dr][0];
   if (s->jit && contact && std_sweeps && s->jit->fn_layout[s->dr] && s->jit->layout_dim == a.layout_dim &&

@@ -38,24 +38,31 @@ constexpr int kWave = 64;
 // the solver settings of the default configuration: kernels built for them have compile-time loop bounds (+2 %).
 // fp64: the exact finish with its lower sweep cap; fp32: sweeps only (kExact* below)
 // (kExact: the exact finish is on, with any positive cap on the solves -- the cap stays a run-time value)
-template <typename T> struct StdSolver { static constexpr int kIters = 14, kNormalIters = 3; static constexpr bool kExact = true; };
-template <> struct StdSolver<float> { static constexpr int kIters = 20, kNormalIters = 3; static constexpr bool kExact = false; };
-template <typename T> __host__ __device__ inline bool is_std_solver(int iters, int normal_iters, int exact) {
-  return iters == StdSolver<T>::kIters && normal_iters == StdSolver<T>::kNormalIters && (exact > 0) == StdSolver<T>::kExact;
+template <typename T> struct StdSolver { static constexpr int kNormalIters = 3; static constexpr bool kExact = true; };
+template <> struct StdSolver<float> { static constexpr int kNormalIters = 3; static constexpr bool kExact = false; };
+// Sweeps before the first check of the exact finish: chosen by same-box A/B per number of dof -- a sweep
+// more takes lanes out of the rounds that one or two lanes of a wave need and costs every wave 3 % of an iteration: it pays
+// for the 5-dof robot (a launch waits for its slowest wave), not for the smaller ones.  kExactRounds re-test sweeps on top.
+#ifdef OS2R_EXACT_FIRST   // (timing experiments only: tools/sessions/r3_first_sweeps*.sh)
+__host__ __device__ constexpr int exact_first(int) { return OS2R_EXACT_FIRST; }
+#else
+__host__ __device__ constexpr int exact_first(int nq) { return nq >= 5 ? 6 : 4; }
+#endif
+constexpr int kExactRounds = 8;
+template <typename T> __host__ __device__ constexpr int std_iters(int nq) { return sizeof(T) == 8 ? exact_first(nq) + kExactRounds : 20; }
+template <typename T> __host__ __device__ inline bool is_std_solver(int iters, int normal_iters, int exact, int nq) {
+  return iters == std_iters<T>(nq) && normal_iters == StdSolver<T>::kNormalIters && (exact > 0) == StdSolver<T>::kExact;
 }
 // Phase-2 sweeps run in groups of kPgsGroup; the last sweep of a group measures the energy it moved
 // (sum over the rows of |residual * impulse change|, the decrease of the QP objective up to a factor <= 2) and an
 // environment whose measure is within pgs_tol stops sweeping.  Per lane: what an
 // environment computes does not depend on the company it keeps in its wave.
 constexpr int kPgsGroup = 4;
-// Exact finish of the fixed-box problem (Os2rConfig.pgs_exact > 0, fp64 only): after kExactFirst
+// Exact finish of the fixed-box problem (Os2rConfig.pgs_exact > 0, fp64 only): after exact_first(nq)
 // sweeps an environment that has not converged solves its free rows exactly -- (S + eps I) d = -G_F^T w_F with
 // S = G_F^T G_F (NQ x NQ whatever the number of free rows), eps = kExactEps * trace S, kExactProx proximal iterations,
 // impulses from the residuals -- cuts the step at the first bound it meets, and re-tests every row with one measured sweep.
-#ifndef OS2R_EXACT_FIRST   // (overridden in timing experiments only: tools/sessions/r3_first_sweeps.sh)
-#define OS2R_EXACT_FIRST 6
-#endif
-constexpr int kExactFirst = OS2R_EXACT_FIRST, kExactProx = 3;
+constexpr int kExactProx = 3;
 constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;
 // An inconsistent free set (more sticking rows than the dof they act on) leaves a residual on its rows and multipliers
 // that move by the same amount round after round: from an environment's second solve of an iteration on, a solve that
@@ -1507,11 +1514,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_ISA_MARK(14);
     return cut;
   };
-  // Phase 2 with the exact finish: kExactFirst sweeps, the last of them measured; from then on an environment that is
+  // Phase 2 with the exact finish: exact_first(NQ) sweeps, the last of them measured; from then on an environment that is
   // still live solves (again while a bound cuts its step short, pgs_exact solves at most per physics iteration) and
   // takes one measured sweep, until the sweep moves no more than pgs_tol or pgs_iters sweeps are spent.
   auto exact_sweeps = [&](auto first) {
     constexpr int kFirst = decltype(first)::value;
+    constexpr int kExactFirst = exact_first(NQ);
     const int nfirst = pgs_iters < kExactFirst ? pgs_iters : kExactFirst;
     for (int k = 0; k + 1 < nfirst; ++k) sweep(std::false_type{}, first, std::false_type{});
     if (nfirst > 0) { moved = T(0); sweep(std::false_type{}, first, std::true_type{}); }

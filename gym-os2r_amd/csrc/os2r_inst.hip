@@ -54,7 +54,7 @@ template <typename MD, bool CONTACT, bool DR>
 static int launch_step(const StepArgs<T>& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave)), block(kWave);
   // the compiled-in robots also exist with the default sweep counts as compile-time loop bounds
-  if (MD::kStatic && is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact)) {
+  if (MD::kStatic && is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact, MD::NQ)) {
 #if OS2R_UNIT < 10
     {
       if (layout_is<LayA>(a)) {

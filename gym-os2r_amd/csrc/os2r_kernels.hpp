@@ -477,7 +477,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
     substep<T, MD, CONTACT, DR, COUNT, SOLVER>(
                                        md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
-                                       STD_SWEEPS ? StdSolver<T>::kIters : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
+                                       STD_SWEEPS ? std_iters<T>(NQ) : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
                                        A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc, hint
 #ifdef OS2R_STAMPS
                                        , stamps, stamp_prev

@@ -648,7 +648,7 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
  * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
  * row and measures what it moved.  At most `exact` solves per physics iteration; the sweep cap `iters` still holds. */
-#define ORC_EXACT_FIRST 6
+#define ORC_EXACT_FIRST(n) ((n) >= 5 ? 6 : 4)   /* sweeps before the first check: per number of dof */
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX 3
 #define ORC_EXACT_SNAP 1e-12
@@ -808,7 +808,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
     for (int it = 0; it < sweeps; ++it) {
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
-      if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST && solves < exact) {
+      if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST(n) && solves < exact) {
         if (solves == 0 && hint && *hint != 0u && g_hints)
           for (int r = 0; r < nr; ++r) {
             Row* R = &rows[r];
@@ -845,7 +845,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
       if (phase == 1 && it + 1 < sweeps && moved <= tol) {
-        if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST : (it + 1) % ORC_PGS_GROUP == 0) break;
+        if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) : (it + 1) % ORC_PGS_GROUP == 0) break;
       }
     }
     if (phase == 1 && hint) {

@@ -105,7 +105,7 @@ def pgs_two_phase(p, normal_iters=3, iters=20, tol=1e-24, group=4):
     return v, lam, box, ran
 
 
-def pgs_exact_finish(p, normal_iters=3, iters=14, tol=1e-24, exact=12, first=6, eps_rel=1e-6, prox=3, snap=1e-12, incons=1e-4):
+def pgs_exact_finish(p, normal_iters=3, iters=None, tol=1e-24, exact=12, first=None, eps_rel=1e-6, prox=3, snap=1e-12, incons=1e-4):
     """The specification's solver with the exact finish, restated on the
     exported rows: phase 1 as in pgs_two_phase; phase 2 = `first` sweeps, then -- while the last sweep moved more than
     `tol` -- exact solves of the free rows (repeated while a bound cuts the step short, `exact` at most) each followed
@@ -114,6 +114,10 @@ def pgs_exact_finish(p, normal_iters=3, iters=14, tol=1e-24, exact=12, first=6, 
     multipliers to the first bound and counts as cut.  -> (v, lam, box, sweeps of phase 2, exact solves)"""
     J, minv, t, kind, nrow = p["J"], p["minv"], p["target"], p["kind"], p["normal_row"]
     nr, n = J.shape
+    if first is None:
+        first = 6 if n >= 5 else 4     # sweeps before the first check: per number of dof
+    if iters is None:
+        iters = first + 8
     Lc = np.linalg.cholesky(minv)
     G = J @ Lc                         # rows in the whitened coordinates y = Lc^-1 v
     d = np.einsum("rk,rk->r", G, G)

@@ -204,7 +204,7 @@ def test_boxed_lcp_solution_against_the_exact_solution(oracle, regime):
     (p99 1e-4 in the balancing regime), which is printed beside it."""
     cfg, states = _hard_problems(oracle, regime)
     import copy
-    assert cfg.pgs_exact > 0 and cfg.pgs_iters == abi.DEFAULT_PGS_ITERS_EXACT
+    assert cfg.pgs_exact > 0 and cfg.pgs_iters == abi.default_pgs_iters_exact(cfg.model.nq)
     legacy = copy.copy(cfg); legacy.pgs_exact = 0; legacy.pgs_iters = abi.DEFAULT_PGS_ITERS
     err_spec, err_legacy, n_enum, resid, solves = [], [], 0, [], []
     for e, st in enumerate(states):
