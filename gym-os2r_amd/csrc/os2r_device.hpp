@@ -49,6 +49,21 @@ __host__ __device__ constexpr int exact_first(int) { return OS2R_EXACT_FIRST; }
 __host__ __device__ constexpr int exact_first(int nq) { return nq >= 5 ? 6 : 4; }
 #endif
 constexpr int kExactRounds = 8;
+// From the second physics iteration of an env-step on, phase 2 starts from the impulses that ended the previous iteration
+// (clamped into this iteration's box; the velocity follows row by row): the solution moves by a thousandth per iteration,
+// so the start is a million times closer in energy and warm_first(nq) sweeps identify the active sets that exact_first(nq)
+// cold sweeps do (same-box A/B).  The first iteration of an env-step is cold.
+#ifdef OS2R_WARM_FIRST   // (timing experiments only)
+__host__ __device__ constexpr int warm_first(int) { return OS2R_WARM_FIRST; }
+#else
+__host__ __device__ constexpr int warm_first(int) { return 3; }
+#endif
+// What the exact finish of an environment carries from one physics iteration of an env-step to the next (registers):
+// the impulses that ended phase 2 and which bodies had a contact.
+template <typename T, int NQ_> struct SolverCarry {
+  unsigned act = 0u;
+  T ln[NQ_], lx[NQ_], ly[NQ_], lf[NQ_];
+};
 template <typename T> __host__ __device__ constexpr int std_iters(int nq) { return sizeof(T) == 8 ? exact_first(nq) + kExactRounds : 20; }
 template <typename T> __host__ __device__ inline bool is_std_solver(int iters, int normal_iters, int exact, int nq) {
   return iters == std_iters<T>(nq) && normal_iters == StdSolver<T>::kNormalIters && (exact > 0) == StdSolver<T>::kExact;
@@ -616,7 +631,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
                                         T (&q)[MD::NQ], T (&qd)[MD::NQ], T (&sn)[MD::NQ], T (&cs)[MD::NQ], bool first_iteration,
                                         T tau_hip, T tau_knee, T dt, T erp,
                                         T max_erv, T margin, int pgs_iters, int pgs_normal_iters, int pgs_exact, T pgs_tol, T* __restrict__ lds,
-                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst, WorkCounts& wc, unsigned& hint
+                                        const T* __restrict__ cand_lds, ModelPtr<T> mconst, WorkCounts& wc, SolverCarry<T, MD::NQ>& carry
 #ifdef OS2R_STAMPS
                                         , unsigned long long (&stamps)[kStamps], unsigned long long& stamp_prev
 #endif
@@ -1519,40 +1534,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // takes one measured sweep, until the sweep moves no more than pgs_tol or pgs_iters sweeps are spent.
   auto exact_sweeps = [&](auto first) {
     constexpr int kFirst = decltype(first)::value;
-    constexpr int kExactFirst = exact_first(NQ);
+    const int kExactFirst = first_iteration ? exact_first(NQ) : warm_first(NQ);   // (wave-uniform)
     const int nfirst = pgs_iters < kExactFirst ? pgs_iters : kExactFirst;
     for (int k = 0; k + 1 < nfirst; ++k) sweep(std::false_type{}, first, std::false_type{});
     if (nfirst > 0) { moved = T(0); sweep(std::false_type{}, first, std::true_type{}); }
     int sweeps = nfirst, solves = 0;
     bool live = nfirst > 0 && moved > tol_v && sweeps < pgs_iters;
-    // Active-set hints between the iterations of an env-step (a contact that slides does so for many iterations, and the
-    // sweeps approach the bound of its tangential impulse from inside without reaching it: the first solve of every
-    // iteration would take the row for sticking, be cut and have to be repeated): the tangential rows that ended the last
-    // iteration on a bound -- two bits per row, slot 2 * body + (0: x, 1: y), bit 0 lower, bit 1 upper -- and that the
-    // sweeps have left strictly inside are put on that bound before the first solve.  A wrong hint costs a round, no more:
-    // the re-test sweep releases the row.
-    if (__ballot(live && hint != 0u) != 0ull) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (!((CMASK >> b) & 1u)) continue;
-        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-        const T lim = limfix[b];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          T& l = t == 0 ? lx[b] : ly[b];
-          const unsigned side = (hint >> (2 * (2 * b + t))) & 3u;
-          if (__ballot(live & (side != 0u)) == 0ull) continue;   // (nearly every row: two or three lanes are live, with a hint or two each)
-          const bool ap = live & (side != 0u) & (l > -lim) & (l < lim) & ((t == 0 ? dx[b] : dy[b]) > T(0));   // (a contact that is not active has lim = 0)
-          if (__ballot(ap) == 0ull) continue;
-          const T nl = side == 2u ? lim : -lim;
-          const T dl = opaque(ap ? nl - l : T(0));
-          l = ap ? nl : l;
-#pragma unroll
-          for (int k = 0; k < NQ; ++k)
-            if (k <= b) y[k] = fma_t(Gr[b][1 + t][k], dl, y[k]);
-        }
-      }
-    }
     if constexpr (COUNT) {
       unsigned nb = 0;
 #pragma unroll
@@ -1595,24 +1582,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         live = moved > tol_v && sweeps < pgs_iters;
       }
     }
-    // what the next iteration is told: an environment that had to solve remembers its tangential rows on a bound
-    unsigned hn = 0u;
-    if (__ballot(solves > 0) != 0ull) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (!((CMASK >> b) & 1u)) continue;
-        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-        const T lim = limfix[b];
-        const bool has = lim > T(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const T l = t == 0 ? lx[b] : ly[b];
-          const unsigned bits = (l <= -lim) ? 1u : ((l >= lim) ? 2u : 0u);
-          hn |= (has ? bits : 0u) << (2 * (2 * b + t));   // (a void row keeps the impulse 0, inside a box with lim > 0)
-        }
-      }
-    }
-    hint = solves > 0 ? hn : 0u;
   };
   int first_act = NB;
   bool is_suffix = true;
@@ -1621,15 +1590,62 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     if (!((CMASK >> b) & 1u)) continue;
     if (wave_act[b]) { is_suffix = is_suffix && first_act == next_cand_body<CMASK, NB>(b); first_act = b; }
   }
+  // The exact finish between its warm start (second iteration of an env-step on) and the impulses it leaves for the next.
+  auto exact_carried = [&](auto first) {
+    constexpr int kFirst = decltype(first)::value;
+    if (!first_iteration) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!((CMASK >> b) & 1u)) continue;
+        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+        const bool ap = ((carry.act >> b) & 1u) != 0u && dn[b] > T(0);   // a contact now and in the last iteration
+        if (__ballot(ap) == 0ull) continue;
+        const T lim = limfix[b];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          T& l = t == 0 ? ln[b] : (t == 1 ? lx[b] : ly[b]);
+          const T prev = t == 0 ? carry.ln[b] : (t == 1 ? carry.lx[b] : carry.ly[b]);
+          T nl = t == 0 ? fmax_t(prev, T(0)) : fmin_t(fmax_t(prev, -lim), lim);
+          nl = ap ? nl : l;
+          const T dl = nl - l;
+          l = nl;
+#pragma unroll
+          for (int k = 0; k < NQ; ++k)
+            if (k <= b) y[k] = fma_t(Gr[b][t][k], dl, y[k]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const T nl = fmin_t(fmax_t(carry.lf[j], -fb[j]), fb[j]);
+        const T dl = nl - lf[j];
+        lf[j] = nl;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+          if (k <= j) y[k] = fma_t(Lc[j][k], dl, y[k]);
+      }
+    }
+    exact_sweeps(first);
+    unsigned act = 0u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+      carry.ln[b] = ln[b]; carry.lx[b] = lx[b]; carry.ly[b] = ly[b];
+      act |= (dn[b] > T(0) ? 1u : 0u) << b;
+    }
+    carry.act = act;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) carry.lf[j] = lf[j];
+  };
   auto solve_fixed_box = [&](auto first) {
     for (int it = 0; it < pgs_normal_iters; ++it) normal_sweep(first);
     OS2R_STAMP(7);
 #pragma unroll
     for (int b = 0; b < NB; ++b) limfix[b] = opaque(mub[b] * ln[b]);   // (a plain value: the exact finish subtracts from it)
     if constexpr (sizeof(T) == 8 && SOLVER == kSolverExact) {
-      exact_sweeps(first);
+      exact_carried(first);
     } else if constexpr (sizeof(T) == 8 && SOLVER == kSolverBoth) {
-      if (pgs_exact > 0) exact_sweeps(first);
+      if (pgs_exact > 0) exact_carried(first);
       else grouped_sweeps(std::false_type{}, first);
     } else {
       grouped_sweeps(std::false_type{}, first);

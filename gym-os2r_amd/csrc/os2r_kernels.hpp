@@ -472,13 +472,13 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 #endif
   T sn[NQ], cs[NQ];   // sin/cos of the joint angles, carried from one physics iteration to the next
   WorkCounts wc;
-  unsigned hint = 0u;   // active-set hints of the exact finish, from one physics iteration to the next (os2r_device.hpp)
+  SolverCarry<T, NQ> carry;   // what the exact finish hands from one physics iteration to the next (os2r_device.hpp)
   for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
     if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
     substep<T, MD, CONTACT, DR, COUNT, SOLVER>(
                                        md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
                                        STD_SWEEPS ? std_iters<T>(NQ) : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
-                                       A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc, hint
+                                       A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc, carry
 #ifdef OS2R_STAMPS
                                        , stamps, stamp_prev
 #endif

@@ -648,7 +648,8 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
  * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
  * row and measures what it moved.  At most `exact` solves per physics iteration; the sweep cap `iters` still holds. */
-#define ORC_EXACT_FIRST(n) ((n) >= 5 ? 6 : 4)   /* sweeps before the first check: per number of dof */
+#define ORC_EXACT_FIRST_STD(n) ((n) >= 5 ? 6 : 4)
+#define ORC_EXACT_FIRST(n) (warm_now ? (g_first_override > 0 ? g_first_override : ORC_WARM_FIRST) : ORC_EXACT_FIRST_STD(n))   /* sweeps before the first check: per number of dof */
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX 3
 #define ORC_EXACT_SNAP 1e-12
@@ -771,22 +772,25 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
 /* diagnostics: phase-2 sweeps and exact solves of the calling thread's last solve (orc_get_solver_counts) */
 static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 
-/* Active-set hints between the physics iterations of one env-step.  A contact that slides does so for many iterations
- * in a row, and Gauss-Seidel approaches the bound of its tangential impulse from inside without reaching it: the first
- * solve of EVERY iteration takes the row for sticking, is cut at the bound and has to be repeated -- and the wave that
- * holds such an environment is the slowest of its launch.  So an environment that had to solve remembers which
- * tangential rows ended the iteration ON a bound, and on which side (two bits per row slot); in the next iteration, if it
- * still needs a solve after the first sweeps, the remembered rows that the sweeps have left strictly inside are put on
- * that bound (of THIS iteration's box) before it solves.  A wrong hint costs work, not accuracy: the re-test sweep
- * releases the row and the environment solves again.
- * slot of a tangential row: 2 * body + (0: x, 1: y);  bit 2 slot: on the lower bound, 2 slot + 1: on the upper bound.
- * Zero at the start of every env-step; an environment that needed no solve forgets. */
-static int hint_slot(const Row* rows, int r) { return rows[r].kind == 1 ? 2 * rows[r].body + (r - rows[r].normal_row - 1) : -1; }
-static int g_hints = 1;   /* experiments and tests: 0 switches the hints off */
-void orc_set_experimental_hints(int on) { g_hints = on; }
+/* Warm start between the physics iterations of one env-step.  From the second iteration on, phase 2 starts from the
+ * impulses that ended the previous iteration (clamped into this iteration's box; rows of a body that had no contact then
+ * keep what phase 1 gave them): the solution moves by a thousandth per iteration, so ORC_WARM_FIRST sweeps identify the
+ * active sets that ORC_EXACT_FIRST_STD cold sweeps do.  The first iteration of an env-step is cold, and so is a single
+ * iteration (orc_substep, orc_contact_problem).  Per thread: an environment's iterations run back to back on one thread.
+ * (orc_set_experimental_warm: studies -- off, or another number of sweeps after a warm start) */
+#define ORC_WARM_FIRST 3
+static int g_warm = 1, g_first_override = 0;
+void orc_set_experimental_warm(int on, int first) { g_warm = on; g_first_override = first; }
+static _Thread_local double tl_warm[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+static _Thread_local int tl_warm_valid = 0;
+static int warm_slot(const Row* rows, int r) {
+  const Row* R = &rows[r];
+  if (R->kind == 0) return 3 * R->body;
+  if (R->kind == 1) return 3 * R->body + (r - R->normal_row);
+  return 3 * OS2R_MAX_DOF + R->body;
+}
 
-static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, int exact, const double* minv, double* v,
-                       uint32_t* hint) {
+static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, int exact, const double* minv, double* v) {
   int order[ORC_MAX_ROWS];
   for (int r = 0; r < nr; ++r) order[r] = r;
   if (g_row_order != 0)
@@ -797,30 +801,30 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         r += 2;
       }
   if (normal_iters <= 0) exact = 0;               /* the coupled pyramid has no fixed box to pivot on */
+  const int warm_now = g_warm && tl_warm_valid && exact > 0;
   double lc[OS2R_MAX_DOF * OS2R_MAX_DOF];
   if (exact > 0) chol_lower(n, minv, lc);
   for (int phase = 0; phase < 2; ++phase) {
     const int sweeps = phase == 0 ? normal_iters : iters;
     if (phase == 1 && normal_iters > 0)
       for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
+    if (phase == 1 && exact > 0 && g_warm && tl_warm_valid && nr <= 3 * OS2R_MAX_DOF + OS2R_MAX_DOF)
+      for (int r = 0; r < nr; ++r) {
+        Row* R = &rows[r];
+        const double w0 = tl_warm[warm_slot(rows, r)];
+        if (!(R->d > 0.0) || isnan(w0)) continue;
+        double lo, hi; row_box(rows, R, 1, &lo, &hi);
+        double nl = w0 < lo ? lo : (w0 > hi ? hi : w0);
+        const double dl = nl - R->lambda;
+        R->lambda = nl;
+        for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
+      }
     int solves = 0;
     if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; }
     for (int it = 0; it < sweeps; ++it) {
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
       if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST(n) && solves < exact) {
-        if (solves == 0 && hint && *hint != 0u && g_hints)
-          for (int r = 0; r < nr; ++r) {
-            Row* R = &rows[r];
-            const int slot = hint_slot(rows, r);
-            if (slot < 0 || !(R->d > 0.0)) continue;
-            const unsigned side = (*hint >> (2 * slot)) & 3u;
-            double lo, hi; row_box(rows, R, 1, &lo, &hi);
-            if (side == 0u || !(R->lambda > lo && R->lambda < hi)) continue;
-            const double nl = side == 2u ? hi : lo, dl = nl - R->lambda;
-            R->lambda = nl;
-            for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
-          }
         int blocked = 1;
         while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; }
         tl_last_solves = solves;
@@ -848,42 +852,33 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) : (it + 1) % ORC_PGS_GROUP == 0) break;
       }
     }
-    if (phase == 1 && hint) {
-      uint32_t hnew = 0u;
-      if (solves > 0)
-        for (int r = 0; r < nr; ++r) {
-          const int slot = hint_slot(rows, r);
-          if (slot < 0 || !(rows[r].d > 0.0)) continue;
-          double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
-          if (!(hi > 0.0)) continue;
-          if (rows[r].lambda <= lo) hnew |= 1u << (2 * slot);
-          else if (rows[r].lambda >= hi) hnew |= 2u << (2 * slot);
-        }
-      *hint = hnew;
+    if (phase == 1 && g_warm && nr <= 3 * OS2R_MAX_DOF + OS2R_MAX_DOF) {
+      for (int k = 0; k < 3 * OS2R_MAX_DOF + OS2R_MAX_DOF; ++k) tl_warm[k] = NAN;
+      for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0) tl_warm[warm_slot(rows, r)] = rows[r].lambda;
+      tl_warm_valid = 1;
     }
   }
 }
 
-static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvParams* ep, double* q, double* qd, const double tau2[2],
-                          uint32_t* hint) {
+static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
   const int n = cfg->model.nq;
   double v[OS2R_MAX_DOF], minv[OS2R_MAX_DOF * OS2R_MAX_DOF];
   if (contact_model == ORC_CONTACT_CENTROID) {
     Row rows[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
     const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
-    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, cfg->pgs_exact, minv, v, hint);
+    solve_rows(n, rows, nr, cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, cfg->pgs_exact, minv, v);
   } else {
     Row* rows = (Row*)malloc(sizeof(Row) * ORC_MAX_ROWS);
     const int nr = build_problem(cfg, contact_model, ep, q, qd, tau2, v, minv, rows);
-    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, 0, minv, v, NULL);
+    solve_rows(n, rows, nr, 0, cfg->pgs_iters, cfg->pgs_tol, 0, minv, v);
     free(rows);
   }
   for (int i = 0; i < n; ++i) { qd[i] = v[i]; q[i] += cfg->dt * v[i]; }
 }
 
 static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
-  uint32_t hint = 0u;   /* a single iteration: nothing to remember */
-  substep_model(cfg, ORC_CONTACT_CENTROID, ep, q, qd, tau2, &hint);
+  tl_warm_valid = 0;   /* a single iteration: nothing remembered */
+  substep_model(cfg, ORC_CONTACT_CENTROID, ep, q, qd, tau2);
 }
 
 static void params_from(const Os2rConfig* cfg, const double* mass_scale, const double* damping, const double* friction,
@@ -907,8 +902,8 @@ void orc_substep_model(const Os2rConfig* cfg, int contact_model, const double* m
                        const double* friction, const double* mu, double gravity_z, double* q, double* qd,
                        const double tau2[2]) {
   EnvParams ep; params_from(cfg, mass_scale, damping, friction, mu, gravity_z, &ep);
-  uint32_t hint = 0u;
-  substep_model(cfg, contact_model, &ep, q, qd, tau2, &hint);
+  tl_warm_valid = 0;
+  substep_model(cfg, contact_model, &ep, q, qd, tau2);
 }
 
 /* The boxed LCP of one physics iteration, laid open for independent checks (tests/test_oracle_contact.py):
@@ -936,7 +931,8 @@ int orc_contact_problem(const Os2rConfig* cfg, int contact_model, const double* 
     for (int i = 0; i < 3; ++i) point[3 * r + i] = rows[r].point[i];
   }
   const int coupled = contact_model != ORC_CONTACT_CENTROID || cfg->pgs_normal_iters == 0;
-  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, coupled ? 0 : cfg->pgs_exact, minv, v, NULL);
+  tl_warm_valid = 0;
+  solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, coupled ? 0 : cfg->pgs_exact, minv, v);
   for (int r = 0; r < nr; ++r) {
     lambda[r] = rows[r].lambda;
     if (rows[r].kind == 0) box[r] = INFINITY;
@@ -1114,9 +1110,9 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
     double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
     EnvParams ep; load_params(s, e, &ep);
     for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
-    uint32_t hint = 0u;
+    tl_warm_valid = 0;
     for (int k = 0; k < cfg->substeps; ++k) {                                                          /* gazebo_runtime.py:70-77 */
-      substep_model(cfg, s->contact_model, &ep, q, qd, tau, &hint);
+      substep_model(cfg, s->contact_model, &ep, q, qd, tau);
       if (s->solver_counts) {
         s->solver_counts[(size_t)k * s->N + e] = (int8_t)(tl_last_sweeps > 127 ? 127 : tl_last_sweeps);
         s->solver_counts[((size_t)cfg->substeps + k) * s->N + e] = (int8_t)(tl_last_solves > 127 ? 127 : tl_last_solves);

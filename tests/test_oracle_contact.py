@@ -334,13 +334,12 @@ def test_closed_loop_solver_error_after_1000_balancing_steps(oracle):
     assert np.median(e_def) <= 1e-7 and np.percentile(e_def, 90) <= 1e-5
 
 
-def test_active_set_hints_save_solves_and_change_nothing(oracle):
-    """Hints between the physics iterations of an env-step: the tangential rows that ended an iteration on
-    a bound are put there before the next iteration's first solve.  From the same steady state of the bench workload, three
-    env-steps with and without them: the states agree to 1e-10 (both end every solve at the exact solution), and the
-    environment-iterations that need a second solve -- a contact that slides through the env-step, cut again in every
-    iteration -- drop by more than a third (measured: 0.46 % -> 0.23 % of the environment-iterations; a wave's solves per
-    env-step 12.2 -> 11.4 on average, 21 -> 17 at p99)."""
+def test_warm_start_between_iterations_saves_sweeps_and_changes_nothing(oracle):
+    """From the second physics iteration of an env-step on, phase 2 starts from the impulses that ended the previous
+    iteration and checks after three sweeps instead of six.  From the same steady state of the bench
+    workload, three env-steps with and without it: the states agree to 1e-10 (both end every solve at the exact solution),
+    more than a quarter of the phase-2 sweeps go (45 % measured), a quarter more environments solve once, and the environment-iterations that need a second or third solve -- a contact that
+    slides through the env-step, taken for sticking again by every cold start -- do not grow."""
     n = 2048
     cfg, task, model = make_config("free_hip", num_envs=n, reset_mode=abi.RESET_RANDOM, randomize_params=True, max_episode_steps=100000,
                                    seed=42, contact=True)
@@ -354,22 +353,23 @@ def test_active_set_hints_save_solves_and_change_nothing(oracle):
     b.set_action_history(0, a.get_action_history(0)); b.set_action_history(1, a.get_action_history(1))
     b.set_episode_info(*a.episode_info())
     b.set_step_count(a.step_count)
-    second = {}
+    counts = {}
     try:
         for sim, on in ((a, 1), (b, 0)):
-            oracle.lib().orc_set_experimental_hints(on)
+            oracle.lib().orc_set_experimental_warm(on, 0)
             sim.solver_counts()
-            cnt = np.zeros(3, dtype=np.int64)
+            cnt = np.zeros(4, dtype=np.int64)
             for _ in range(3):
                 sim.step(None)
                 sw, so = sim.solver_counts()
-                cnt += np.array([(so >= 1).sum(), (so >= 2).sum(), so.sum()])
-            second[on] = cnt
+                cnt += np.array([(so >= 1).sum(), (so >= 2).sum(), so.sum(), sw.astype(np.int64).sum()])
+            counts[on] = cnt
     finally:
-        oracle.lib().orc_set_experimental_hints(1)
+        oracle.lib().orc_set_experimental_warm(1, 0)
     qa, va = a.get_state(); qb, vb = b.get_state()
     err = max(np.max(np.abs(qa - qb) / np.maximum(np.abs(qb), 1.0)), np.max(np.abs(va - vb) / np.maximum(np.abs(vb), 1.0)))
-    print(f"[hints] env-iterations with a solve / with two or more / solves in all: with hints {second[1]}, without {second[0]}; states differ by {err:.1e}")
+    print(f"[warm start] env-iterations with a solve / with two or more / solves in all / phase-2 sweeps in all: warm {counts[1]}, cold {counts[0]}; "
+          f"states differ by {err:.1e}")
     assert err <= 1e-10
-    assert second[1][1] <= 0.67 * second[0][1] and second[1][2] < second[0][2]
+    assert counts[1][3] <= 0.72 * counts[0][3] and counts[1][1] <= counts[0][1] and counts[1][2] <= 1.4 * counts[0][2]
     a.close(); b.close()
