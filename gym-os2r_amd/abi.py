@@ -35,8 +35,8 @@ DEFAULT_PGS_ITERS, DEFAULT_PGS_EXACT = 20, 12
 
 
 def default_pgs_iters_exact(nq: int) -> int:
-    """Sweep cap of the exact finish: the sweeps before the first check (six for the 5-dof robot, four for the smaller
-    ones: csrc/os2r_device.hpp exact_first) plus eight re-test sweeps.  The kernels built for these settings have
+    """Sweep cap of the exact finish: the sweeps before the first check after a cold start (six for the 5-dof robot, four
+    for the smaller ones: csrc/os2r_device.hpp exact_first; three after a warm start) plus eight re-test sweeps.  The kernels built for these settings have
     compile-time loop bounds."""
     return (6 if int(nq) >= 5 else 4) + 8
 

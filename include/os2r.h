@@ -168,8 +168,9 @@ typedef struct Os2rConfig {
   double pgs_tol;          /* an environment stops sweeping once a checked sweep moved no more     */
                            /*   energy than this [J]; 0: exact fixed points only                   */
   int32_t pgs_exact;       /* exact finish of the boxed LCP: an environment that   */
-                           /*   has not converged after the first 6 sweeps of phase 2 (4 for robots  */
-                           /*   with fewer than five dof) solves its                                */
+                           /*   has not converged after the first sweeps of phase 2 (6 in the first  */
+                           /*   iteration of a step, 4 for robots with fewer than five dof; 3 in    */
+                           /*   the later ones, which start from the previous impulses) solves its  */
                            /*   free rows exactly (a 5x5 system in the whitened velocities), with  */
                            /*   active-set pivots (a step cut at a bound; an inconsistent free set */
                            /*   left by a step to the first bound), at most this many solves per   */

@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Who makes the slow waves of a launch?  
 
-  python tests/diag/wave_solves.py [--workload C4|C3|V1] [--envs 16384] [--steps 10] [--hints 1|0] [--show 6]
+  python tests/diag/wave_solves.py [--workload C4|C3|V1] [--envs 16384] [--steps 10] [--warm 1|0] [--first K] [--show 6]
 
 Rolls the bench workload into its stationary regime with the CPU oracle and reads the oracle's solver diagnostics -- the
 phase-2 sweeps and exact solves of every (environment, physics iteration) -- as the kernel would experience them: 64
 consecutive environments are a wave, a wave runs as many solve rounds in an iteration as the slowest of its lanes, and a
 launch lasts as long as its slowest wave.  Prints the distribution of a wave's solves and re-test sweeps per env-step,
 the environment-iteration histogram, and for the slowest waves which lane drove each iteration (one lane whose first
-solve is cut in every iteration = a contact that slides through the env-step: what the hints of DESIGN.md 3.2 are for;
---hints 0 switches them off in the oracle for comparison)."""
+solve is cut in every iteration = a contact that slides through the env-step and that every cold start takes for sticking:
+what the warm start of DESIGN.md 3.2 removes; --warm 0 switches it off in the oracle, --first K sets the sweeps before the
+first check after a warm start, for comparison)."""
 import argparse
 import os
 import sys
@@ -29,7 +30,8 @@ def main():
     ap.add_argument("--envs", type=int, default=16384)
     ap.add_argument("--preroll", type=int, default=600)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--hints", type=int, default=1)
+    ap.add_argument("--warm", type=int, default=1)
+    ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--show", type=int, default=6)
     a = ap.parse_args()
 
@@ -38,7 +40,7 @@ def main():
         pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
     O.build()
-    O.lib().orc_set_experimental_hints(int(a.hints))
+    O.lib().orc_set_experimental_warm(int(a.warm), int(a.first))
     o = O.OracleSim(cfg, threads=os.cpu_count() or 1)
     for _ in range(a.preroll):
         o.step(None)
@@ -57,7 +59,7 @@ def main():
         hist += np.bincount(so.ravel(), minlength=16)[:16]
         last = (sw, so)
     T, R = np.concatenate(tots), np.concatenate(rounds) - first * cfg.substeps
-    print(f"{a.workload}, {cfg.num_envs} envs = {W} waves, {a.steps} env-steps after {a.preroll}, hints {'on' if a.hints else 'off'}")
+    print(f"{a.workload}, {cfg.num_envs} envs = {W} waves, {a.steps} env-steps after {a.preroll}, warm start {'on' if a.warm else 'off'}")
     print(f"  exact solves per wave and env-step: mean {T.mean():.2f}  p50 {np.percentile(T, 50):.0f}  p90 {np.percentile(T, 90):.0f}  "
           f"p99 {np.percentile(T, 99):.0f}  max {T.max()};  re-test sweeps: mean {R.mean():.2f}  p99 {np.percentile(R, 99):.0f}  max {R.max()}")
     print(f"  (environment, iteration) pairs by number of solves: {hist[:np.max(np.nonzero(hist)) + 1]}")
@@ -69,7 +71,7 @@ def main():
         am = so[:, w, :].argmax(axis=1)
         lane = np.bincount(am).argmax()
         print(f"  wave {w}: {tot[w]} solves; per iteration {so[:, w, :].max(axis=1)}; driven by lanes {am}; lane {lane}: solves {so[:, w, lane]} sweeps {sw[:, w, lane]}")
-    O.lib().orc_set_experimental_hints(1)
+    O.lib().orc_set_experimental_warm(1, 0)
 
 
 if __name__ == "__main__":
