@@ -89,6 +89,11 @@ def algorithmic_bytes_per_env_step(cfg, esz):
     if dr:
         reads += (4 * nq + 1) * esz                   # mass scale, damping, friction, mu, gravity
     writes = (2 * nq + 4) * esz + 2 * D * esz + esz + 1 + 4  # q, qd, action history x2; obs and terminal obs; reward; done; steps
+    if esz == 8 and cfg.pgs_exact > 0 and cfg.pgs_normal_iters > 0:
+        # the contact solver's state (round 4): impulses of the contacts of the bodies that can touch + joint impulses + flags, in and out
+        bodies = len({int(cfg.model.cand_body[k]) for k in range(int(cfg.model.ncand))}) if cfg.contact else 0
+        reads += (3 * bodies + nq) * esz + 4
+        writes += 4 * nq * esz + 4
     return reads + writes
 
 
@@ -161,6 +166,7 @@ def counted_flops(sims, cks, steps, dr, workload, skip=0):
     for sim, ck in zip(sims, cks):
         try:
             sim.set_state(ck["q"], ck["qd"])
+            sim.set_solver_state(ck["solver_lambda"], ck["solver_flags"])
             sim.set_action_history(0, ck["hist0"]); sim.set_action_history(1, ck["hist1"])
             if dr:                                    # (restoring parameters would switch a nominal handle to per-env ones)
                 for f, v in ck["params"].items():
@@ -217,7 +223,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--pgs-iters", type=int, default=None, help="cap on the phase-2 sweeps (default: abi.config_struct's: 12 with the exact finish, 20 without)")
+    ap.add_argument("--pgs-iters", type=int, default=None, help="cap on the phase-2 sweeps (default: abi.config_struct's: 14 with the exact finish -- 12 below five dof --, 20 without)")
     ap.add_argument("--pgs-exact", type=int, default=None, help="exact free-set solves per physics iteration at most (default 12 in f64; 0: sweeps only, the round-2 solver)")
     ap.add_argument("--pgs-normal-iters", type=int, default=3)
     ap.add_argument("--pgs-tol", type=float, default=None,
@@ -240,6 +246,10 @@ def main():
                          "independently (a shard waits for its own slowest wave only; DESIGN.md 7).  Results per environment "
                          "are those of the single batch, bit for bit.  Pays over long rollouts, once the shards have drifted out of "
                          "phase (+7 % with 4 shards over 1000 steps, nothing over 20); default 1: one handle, one launch per env-step")
+    ap.add_argument("--rollout", type=int, default=0, metavar="K",
+                    help="a SEPARATE measurement, never the headline: advance in open-loop rollouts of K env-steps per launch "
+                         "(os2r_rollout: every wave steps its own environments K times, no device-wide barrier per env-step) instead "
+                         "of one launch per env-step; --steps is rounded down to a multiple of K")
     ap.add_argument("--gather-obs", action="store_true",
                     help="also gather obs / reward / done of every step to rank 0 (the optional RCCL collective of "
                          "SURVEY 8e; off the step path, so off by default): one launch + one gather per step")
@@ -259,6 +269,9 @@ def main():
 
     if args.gather_obs:
         args.splits = 1                               # the gather experiment times one launch + one gather per step
+    if args.rollout > 0:
+        args.splits, args.gather_obs = 1, False
+        args.steps = max(args.rollout, args.steps // args.rollout * args.rollout)
     if args.splits > 1:
         # one hardware queue per shard stream (the HIP runtime maps streams onto GPU_MAX_HW_QUEUES queues, 4 by default,
         # and two shards that share a queue run one after the other: 311 instead of 157 us per step with four shards);
@@ -312,7 +325,7 @@ def main():
             if args.warmup > 0:
                 sims[i].bench_enqueue(args.warmup)
     torch.cuda.synchronize()
-    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64"
+    count = rank == 0 and not args.no_count and not args.gather_obs and args.dtype == "f64" and args.rollout == 0
     for _ in range(3 if use_dist else 0):
         barrier()                                     # communicator set-up and first-use costs of the barrier itself stay outside
     cks = [s_.checkpoint() for s_ in sims] if count else None   # for the counting replay of the timed window
@@ -337,6 +350,20 @@ def main():
             evs[i][1].record(streams[i])
         torch.cuda.synchronize()
         kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / S   # mean over the shards of (K launches of that shard)
+    elif args.rollout > 0:
+        # open-loop rollouts of K env-steps per launch, device-drawn actions, every output of every step written
+        K = args.rollout
+        obs_k = torch.empty(K, sim.N, sim.D, dtype=sim.dtype, device=sim.device)
+        term_k = torch.empty_like(obs_k)
+        rew_k = torch.empty(K, sim.N, dtype=sim.dtype, device=sim.device)
+        done_k = torch.empty(K, sim.N, dtype=torch.uint8, device=sim.device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(args.steps // K):
+            sim.rollout_into(K, None, obs_k, rew_k, done_k, term_k)
+        ev1.record()
+        torch.cuda.synchronize()
+        kernel_ms = ev0.elapsed_time(ev1)
     elif not args.gather_obs:
         kernel_ms = sim.bench_steps(args.steps)       # K launches, HIP events on the launch stream
     else:
@@ -363,11 +390,12 @@ def main():
             stepped = torch.cuda.Event()
             stepped.record(main)
             if host:
-                gathered = [gather_to_rank0(t.cpu(), n * world) for t in bufs[b]]
+                gathered = [gather_to_rank0(t.cpu(), n * world, key=nm) for t, nm in zip(bufs[b], ("obs", "reward", "done"))]
             else:
                 side.wait_event(stepped)
                 with torch.cuda.stream(side):
-                    gathered = [gather_to_rank0(t, n * world) for t in bufs[b]]
+                    # (rank 0's [world * n, ...] outputs are allocated once, the collective writes into their slices)
+                    gathered = [gather_to_rank0(t, n * world, key=nm) for t, nm in zip(bufs[b], ("obs", "reward", "done"))]
                     free[b] = torch.cuda.Event()
                     free[b].record(side)
         ev1.record()
@@ -392,12 +420,12 @@ def main():
     total_envs = args.envs_per_gpu * world
     value = total_envs * args.steps / elapsed
     if rank == 0:
-        per_launch_s = kernel_ms * 1e-3 / args.steps
+        per_launch_s = kernel_ms * 1e-3 / args.steps     # (per env-step of the batch; a rollout launch makes --rollout of them)
         bytes_launch = algorithmic_bytes_per_env_step(cfg, esz) * args.envs_per_gpu
         achieved = bytes_launch / per_launch_s / 1e9
         traffic = load_json("traffic.json")
         out = {
-            "metric": "env-steps/sec (aggregate) monopod balance task",
+            "metric": "env-steps/sec (aggregate) monopod balance task" + (f", open-loop rollouts of {args.rollout} env-steps per launch (not the headline)" if args.rollout > 0 else ""),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -409,7 +437,7 @@ def main():
                        "actions": "U(-1,1) Philox on device",
                        "sharding": f"envs x{world}, " + ("obs/reward/done gathered to rank 0 every step (side stream, double-buffered)" if args.gather_obs else "no step-path collective"),
                        "n_ranks_seen": dist.get_world_size() if use_dist else 1,
-                       "splits": S},
+                       "splits": S, "rollout_steps_per_launch": args.rollout if args.rollout > 0 else 1},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),

@@ -17,7 +17,7 @@ _lib = None
 
 # every symbol include/os2r.h declares
 SYMBOLS = ["os2r_abi_version", "os2r_create", "os2r_destroy", "os2r_reset", "os2r_step",
-           "os2r_get_state", "os2r_set_state", "os2r_get_action_history", "os2r_set_action_history",
+           "os2r_rollout", "os2r_get_state", "os2r_set_state", "os2r_get_solver_state", "os2r_set_solver_state", "os2r_get_action_history", "os2r_set_action_history",
            "os2r_set_params", "os2r_get_params", "os2r_get_episode_info", "os2r_set_episode_info", "os2r_get_action_violations",
            "os2r_get_step_count",
            "os2r_set_step_count", "os2r_bench_steps", "os2r_bench_steps_multi", "os2r_set_work_counters", "os2r_set_done_reasons", "os2r_model_is_compiled_in",
@@ -43,6 +43,9 @@ def load():
     lib.os2r_destroy.argtypes = [vp]
     lib.os2r_reset.argtypes = [vp, u8p, vp, vp]
     lib.os2r_step.argtypes = [vp, vp, vp, vp, u8p, vp, vp]
+    lib.os2r_rollout.argtypes = [vp, C.c_int, vp, vp, vp, u8p, vp, vp, vp]
+    lib.os2r_get_solver_state.argtypes = [vp, vp, vp, vp]
+    lib.os2r_set_solver_state.argtypes = [vp, vp, vp, vp]
     lib.os2r_get_state.argtypes = [vp, vp, vp, vp]
     lib.os2r_set_state.argtypes = [vp, vp, vp, vp]
     lib.os2r_get_action_history.argtypes = [vp, C.c_int, vp, vp]
@@ -55,6 +58,7 @@ def load():
     lib.os2r_get_step_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.os2r_set_step_count.argtypes = [vp, C.c_uint64]
     lib.os2r_bench_steps.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_float)]
+    lib.os2r_bench_steps_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
     lib.os2r_set_work_counters.argtypes = [vp, vp]
     lib.os2r_set_done_reasons.argtypes = [vp, vp]
     lib.os2r_model_is_compiled_in.argtypes = [C.POINTER(abi.Os2rModel)]

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Mapping, Optional
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DOF = 5
 MAX_CAND = 192
 MAX_OBS = 12
@@ -35,9 +35,9 @@ DEFAULT_PGS_ITERS, DEFAULT_PGS_EXACT = 20, 12
 
 
 def default_pgs_iters_exact(nq: int) -> int:
-    """Sweep cap of the exact finish: the sweeps before the first check after a cold start (six for the 5-dof robot, four
-    for the smaller ones: csrc/os2r_device.hpp exact_first; three after a warm start) plus eight re-test sweeps.  The kernels built for these settings have
-    compile-time loop bounds."""
+    """Sweep cap of the exact finish (csrc/os2r_device.hpp sweep_cap_base + kExactRounds): 14 for the 5-dof robot, 12 for the
+    smaller ones -- the three sweeps before the first check and the re-test sweeps together.  The kernels built for these
+    settings have compile-time loop bounds."""
     return (6 if int(nq) >= 5 else 4) + 8
 
 
@@ -245,7 +245,8 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     if pgs_exact is None:
         pgs_exact = DEFAULT_PGS_EXACT if dtype == F64 and pgs_normal_iters > 0 else 0
     if pgs_iters is None:
-        pgs_iters = default_pgs_iters_exact(int(model_struct(model).nq)) if pgs_exact > 0 else DEFAULT_PGS_ITERS
+        # (the exact finish runs only on the fixed box: with pgs_normal_iters == 0, the coupled pyramid, the library ignores pgs_exact)
+        pgs_iters = default_pgs_iters_exact(int(model_struct(model).nq)) if pgs_exact > 0 and pgs_normal_iters > 0 else DEFAULT_PGS_ITERS
     c.pgs_iters = int(pgs_iters)
     c.pgs_exact = int(pgs_exact)
     c.pgs_normal_iters = int(pgs_normal_iters)

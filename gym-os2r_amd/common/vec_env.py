@@ -53,7 +53,7 @@ class HipVecEnv:
         env, st = self.envs[i], self._stream_of(i)
         if st is None:
             out = env.step(actions)
-            self._pending[i] = (*out, None)
+            self._pending[i] = (*out, None, None)
             return
         cur = torch.cuda.current_stream(st.device)
         st.wait_stream(cur)                           # the actions were produced on the caller's stream
@@ -61,13 +61,18 @@ class HipVecEnv:
             out = env.step(actions)
             ev = torch.cuda.Event()
             ev.record(st)
-        self._pending[i] = (*out, ev)
+        # The shard's kernel reads the caller's tensor (or a view of it) on the shard's stream: the caching allocator must
+        # not hand its block to the caller's stream again before that launch is done (the caller may drop or reassign
+        # `actions` while evaluating the policy of another shard), and a reference is held until the results are collected.
+        if isinstance(actions, torch.Tensor) and actions.is_cuda:
+            actions.record_stream(st)
+        self._pending[i] = (*out, ev, actions)
 
     def _collect(self, i):
         import torch
         if self._pending[i] is None:
             raise RuntimeError("step_wait() without a step_async() in flight")
-        obs, rew, done, info, ev = self._pending[i]
+        obs, rew, done, info, ev = self._pending[i][:5]
         self._pending[i] = None
         if ev is not None:
             cur = torch.cuda.current_stream(obs.device)
@@ -115,10 +120,23 @@ class HipVecEnv:
         return self.step_wait()
 
     def reset(self):
+        if any(p is not None for p in self._pending):
+            raise RuntimeError("reset() with a step_async() in flight: collect it with step_wait() first")
         if self.num_splits == 1:
             return self.env.reset()
         import torch
-        return torch.cat([e.reset() for e in self.envs])
+        # every shard resets on its own stream, behind whatever it was last given, and the caller's stream waits for all
+        cur = torch.cuda.current_stream(self.envs[0].unwrapped.sim.device)
+        out = []
+        for i, e in enumerate(self.envs):
+            st = self._stream_of(i)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                o = e.reset()
+            cur.wait_stream(st)
+            o.record_stream(cur)
+            out.append(o)
+        return torch.cat(out)
 
     def seed(self, seed=None):
         """SubprocVecEnv seeds worker r with seed + r (subproc_vec_env.py:160-164); here every random stream is keyed

@@ -99,6 +99,8 @@ struct SimBase {
   int32_t* steps = nullptr;
   uint32_t* episode = nullptr;
   uint8_t* pose = nullptr;
+  void* solver_l = nullptr;          // [4*nq][N]: the contact solver's state (os2r_get/set_solver_state)
+  uint32_t* solver_flags = nullptr;  // [N]
   unsigned int* violations = nullptr;
   // scratch outputs for os2r_bench_steps
   void *b_obs = nullptr, *b_rew = nullptr, *b_term = nullptr;
@@ -247,6 +249,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.seed = s->cfg.seed;
   a.step_count = s->step_count;
   a.substeps = s->cfg.substeps;
+  a.rollout_steps = 0;
   a.pgs_iters = s->cfg.pgs_iters;
   a.pgs_normal_iters = s->cfg.pgs_normal_iters;
   a.pgs_exact = s->cfg.pgs_normal_iters > 0 ? s->cfg.pgs_exact : 0;   // the coupled pyramid has no fixed box to pivot on
@@ -259,6 +262,7 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.mass_scale = (T*)s->mass_scale; a.damping = (T*)s->damping; a.friction = (T*)s->friction;
   a.mu = (T*)s->mu; a.gravity = (T*)s->gravity;
   a.steps = s->steps; a.episode = s->episode; a.pose = s->pose; a.violations = s->violations;
+  a.solver_l = (T*)s->solver_l; a.solver_flags = s->solver_flags;
   a.debug = s->debug;
   a.reason = s->reason;
   task_layout(s->cfg.task, a.layout_kinds, a.layout_srcs, a.layout_dim);
@@ -301,6 +305,35 @@ int do_step(Os2rSim* s, const void* actions, void* obs, void* reward, uint8_t* d
   HIP_TRY(s, hipGetLastError());
   s->step_count += 1;
   return OS2R_OK;
+}
+
+// K env-steps: one launch of a fused variant where one exists, K launches of the step kernel otherwise (same results)
+template <typename T>
+int do_rollout(Os2rSim* s, int K, const void* actions, void* obs, void* reward, uint8_t* done, void* term, uint16_t* reason,
+               hipStream_t st) {
+  const size_t N = (size_t)s->cfg.num_envs, D = (size_t)s->D;
+  if (!s->jit && !s->counters) {
+    StepArgs<T> a = make_args<T>(s);
+    a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
+    a.reason = reason;
+    a.rollout_steps = K;
+    const int rc = Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st);
+    if (rc == 0) {
+      HIP_TRY(s, hipGetLastError());
+      s->step_count += (unsigned long long)K;
+      return OS2R_OK;
+    }
+  }
+  uint16_t* const reason_keep = s->reason;
+  int rc = OS2R_OK;
+  for (int k = 0; k < K && rc == OS2R_OK; ++k) {
+    s->reason = reason ? reason + (size_t)k * N : nullptr;
+    rc = do_step<T>(s, actions ? (const T*)actions + (size_t)k * N * 2 : nullptr, obs ? (T*)obs + (size_t)k * N * D : nullptr,
+                    reward ? (T*)reward + (size_t)k * N : nullptr, done ? done + (size_t)k * N : nullptr,
+                    term ? (T*)term + (size_t)k * N * D : nullptr, st);
+  }
+  s->reason = reason_keep;
+  return rc;
 }
 
 template <typename T>
@@ -401,6 +434,8 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
   if ((rc = dev_alloc(s, (void**)&s->steps, N * 4))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->episode, N * 4))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->pose, N))) return fail(rc);
+  if ((rc = dev_alloc(s, &s->solver_l, 4 * n * N * e))) return fail(rc);
+  if ((rc = dev_alloc(s, (void**)&s->solver_flags, N * 4))) return fail(rc);
   if ((rc = dev_alloc(s, (void**)&s->violations, 4))) return fail(rc);
   if ((rc = dev_alloc(s, &s->b_obs, (size_t)s->D * N * e))) return fail(rc);
   if ((rc = dev_alloc(s, &s->b_rew, N * e))) return fail(rc);
@@ -456,6 +491,15 @@ int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward
              : do_step<float>(sim, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, (hipStream_t)stream);
 }
 
+int os2r_rollout(Os2rSim* sim, int nsteps, const void* actions_dev, void* obs_dev, void* reward_dev, uint8_t* done_dev,
+                 void* term_obs_dev, uint16_t* reason_dev, void* stream) {
+  if (!sim || nsteps < 1) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
+  return sim->cfg.dtype == OS2R_F64
+             ? do_rollout<double>(sim, nsteps, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, reason_dev, (hipStream_t)stream)
+             : do_rollout<float>(sim, nsteps, actions_dev, obs_dev, reward_dev, done_dev, term_obs_dev, reason_dev, (hipStream_t)stream);
+}
+
 int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream) {
   if (!sim) return OS2R_ERR_INVALID;
   DeviceGuard guard(sim->cfg.device);
@@ -471,6 +515,27 @@ int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* st
   const size_t b = (size_t)sim->nq * sim->cfg.num_envs * sim->esz;
   if (q_dev) HIP_TRY(sim, hipMemcpyAsync(sim->q, q_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   if (qd_dev) HIP_TRY(sim, hipMemcpyAsync(sim->qd, qd_dev, b, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  // a state set from outside starts like a reset: the contact solver remembers nothing (os2r_set_solver_state restores it)
+  HIP_TRY(sim, hipMemsetAsync(sim->solver_flags, 0, (size_t)sim->cfg.num_envs * 4, (hipStream_t)stream));
+  HIP_TRY(sim, hipMemsetAsync(sim->solver_l, 0, 4 * b, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_get_solver_state(Os2rSim* sim, void* lambda_dev, uint32_t* flags_dev, void* stream) {
+  if (!sim) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
+  const size_t N = (size_t)sim->cfg.num_envs;
+  if (lambda_dev) HIP_TRY(sim, hipMemcpyAsync(lambda_dev, sim->solver_l, 4 * (size_t)sim->nq * N * sim->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (flags_dev) HIP_TRY(sim, hipMemcpyAsync(flags_dev, sim->solver_flags, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return OS2R_OK;
+}
+
+int os2r_set_solver_state(Os2rSim* sim, const void* lambda_dev, const uint32_t* flags_dev, void* stream) {
+  if (!sim || !lambda_dev || !flags_dev) return OS2R_ERR_INVALID;
+  DeviceGuard guard(sim->cfg.device);
+  const size_t N = (size_t)sim->cfg.num_envs;
+  HIP_TRY(sim, hipMemcpyAsync(sim->solver_l, lambda_dev, 4 * (size_t)sim->nq * N * sim->esz, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(sim, hipMemcpyAsync(sim->solver_flags, flags_dev, N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return OS2R_OK;
 }
 
@@ -628,7 +693,7 @@ int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev) {
 
 #ifdef OS2R_STAMPS
 // diagnostic builds only (libos2r_stamps.so): per-wave phase stamps, kStamps x uint64 per workgroup
-int os2r_debug_set_stamp_buffer(Os2rSim* sim, unsigned long long* buf_dev) {
+OS2R_API int os2r_debug_set_stamp_buffer(Os2rSim* sim, unsigned long long* buf_dev) {
   if (!sim) return OS2R_ERR_INVALID;
   sim->debug = buf_dev;
   return OS2R_OK;

@@ -40,31 +40,30 @@ constexpr int kWave = 64;
 // (kExact: the exact finish is on, with any positive cap on the solves -- the cap stays a run-time value)
 template <typename T> struct StdSolver { static constexpr int kNormalIters = 3; static constexpr bool kExact = true; };
 template <> struct StdSolver<float> { static constexpr int kNormalIters = 3; static constexpr bool kExact = false; };
-// Sweeps before the first check of the exact finish: chosen by same-box A/B per number of dof -- a sweep
-// more takes lanes out of the rounds that one or two lanes of a wave need and costs every wave 3 % of an iteration: it pays
-// for the 5-dof robot (a launch waits for its slowest wave), not for the smaller ones.  kExactRounds re-test sweeps on top.
-#ifdef OS2R_EXACT_FIRST   // (timing experiments only: tools/sessions/r3_first_sweeps*.sh)
-__host__ __device__ constexpr int exact_first(int) { return OS2R_EXACT_FIRST; }
-#else
-__host__ __device__ constexpr int exact_first(int nq) { return nq >= 5 ? 6 : 4; }
-#endif
-constexpr int kExactRounds = 8;
-// From the second physics iteration of an env-step on, phase 2 starts from the impulses that ended the previous iteration
-// (clamped into this iteration's box; the velocity follows row by row): the solution moves by a thousandth per iteration,
-// so the start is a million times closer in energy and warm_first(nq) sweeps identify the active sets that exact_first(nq)
-// cold sweeps do (same-box A/B).  The first iteration of an env-step is cold.
+// The solver state of an environment (round 4): phase 2 of every physics iteration starts from the impulses that ended
+// the environment's previous iteration -- of this env-step or of the one before: the state lives in HBM between the
+// launches (StepArgs::solver_l / solver_flags, os2r_get/set_solver_state), as the reference's backend keeps one persistent
+// constraint solver per world behind gym_os2r/runtimes/gazebo_runtime.py:76,111-114 -- clamped into this iteration's box,
+// the velocity following row by row; a row without a remembered impulse (a body that had no contact then; every row
+// after a reset) keeps what phase 1 gave it.  The solution moves by a thousandth per iteration, so warm_first(nq) sweeps
+// identify the active set before the first check (same-box A/B of 2 / 3 / 4 sweeps in round 3).
 #ifdef OS2R_WARM_FIRST   // (timing experiments only)
 __host__ __device__ constexpr int warm_first(int) { return OS2R_WARM_FIRST; }
 #else
 __host__ __device__ constexpr int warm_first(int) { return 3; }
 #endif
-// What the exact finish of an environment carries from one physics iteration of an env-step to the next (registers):
-// the impulses that ended phase 2 and which bodies had a contact.
+// The default cap on the sweeps of phase 2 (first sweeps and re-test sweeps together): sweep_cap_base(nq) + kExactRounds
+// (the numbers of round 3, whose cold first iteration ran sweep_cap_base(nq) sweeps before its first check)
+__host__ __device__ constexpr int sweep_cap_base(int nq) { return nq >= 5 ? 6 : 4; }
+constexpr int kExactRounds = 8;
+// flags: bit b -- body b had a contact in the environment's last physics iteration (its three impulses are remembered);
+// kCarryJoints -- an iteration has run since the reset (the joint-friction impulses are remembered)
+constexpr unsigned kCarryJoints = 0x80000000u;
 template <typename T, int NQ_> struct SolverCarry {
   unsigned act = 0u;
-  T ln[NQ_], lx[NQ_], ly[NQ_], lf[NQ_];
+  T ln[NQ_] = {}, lx[NQ_] = {}, ly[NQ_] = {}, lf[NQ_] = {};
 };
-template <typename T> __host__ __device__ constexpr int std_iters(int nq) { return sizeof(T) == 8 ? exact_first(nq) + kExactRounds : 20; }
+template <typename T> __host__ __device__ constexpr int std_iters(int nq) { return sizeof(T) == 8 ? sweep_cap_base(nq) + kExactRounds : 20; }
 template <typename T> __host__ __device__ inline bool is_std_solver(int iters, int normal_iters, int exact, int nq) {
   return iters == std_iters<T>(nq) && normal_iters == StdSolver<T>::kNormalIters && (exact > 0) == StdSolver<T>::kExact;
 }
@@ -73,7 +72,7 @@ template <typename T> __host__ __device__ inline bool is_std_solver(int iters, i
 // environment whose measure is within pgs_tol stops sweeping.  Per lane: what an
 // environment computes does not depend on the company it keeps in its wave.
 constexpr int kPgsGroup = 4;
-// Exact finish of the fixed-box problem (Os2rConfig.pgs_exact > 0, fp64 only): after exact_first(nq)
+// Exact finish of the fixed-box problem (Os2rConfig.pgs_exact > 0, fp64 only): after warm_first(nq)
 // sweeps an environment that has not converged solves its free rows exactly -- (S + eps I) d = -G_F^T w_F with
 // S = G_F^T G_F (NQ x NQ whatever the number of free rows), eps = kExactEps * trace S, kExactProx proximal iterations,
 // impulses from the residuals -- cuts the step at the first bound it meets, and re-tests every row with one measured sweep.
@@ -169,6 +168,7 @@ struct StepArgs {
   unsigned long long seed;
   unsigned long long step_count;
   int substeps;
+  int rollout_steps;   // env-steps of this launch (os2r_rollout; 1 for os2r_step)
   int pgs_iters;
   int pgs_normal_iters;
   int pgs_exact;
@@ -187,6 +187,8 @@ struct StepArgs {
   int32_t* __restrict__ steps;
   uint32_t* __restrict__ episode;
   uint8_t* __restrict__ pose;
+  T* __restrict__ solver_l;          // [4*nq][N] impulses that ended the environment's last physics iteration (SolverCarry)
+  uint32_t* __restrict__ solver_flags;  // [N] which of them are remembered
   unsigned int* __restrict__ violations;  // count of out-of-range caller actions (nullable)
   // step I/O
   const T* __restrict__ actions;  // [N][2] or null
@@ -517,25 +519,20 @@ struct Params<T, MD, false> {
   __device__ __forceinline__ T mu(int i) const { return m.mu(i); }
   __device__ __forceinline__ T gravity() const { return g; }
 };
-// Randomised parameters are read from their HBM arrays at the point of use (one coalesced load
-// per value and physics iteration, L2-resident after the first) instead of being held in 42
-// registers for the whole kernel.
+// Randomised parameters wait in per-lane LDS slots (round 4; lds[(field * NQ + i) * 64 + lane], written once per env-step
+// by the step kernel: body masses already multiplied out): a physics iteration reads them where it uses them with one
+// ds_read each -- no address arithmetic, no base pointers re-fetched from the argument segment, 21 L2 round trips fewer
+// per iteration than reading the HBM arrays at the point of use (rounds 1-3), and still no registers held across the kernel.
 template <typename T, typename MD>
 struct Params<T, MD, true> {
   MD m;
-  // global address space on purpose: generic pointers turn into flat_load, whose completions are
-  // unordered, so every wait degenerates to vmcnt(0) and also waits for requests just issued
-  using GP = const __attribute__((address_space(1))) T*;
-  GP ms;  // [nq][N] each
-  GP dm;
-  GP fr;
-  GP mu_;
-  long long N, e;
+  const T* slots;   // this lane's column of the parameter slots
   T g;
-  __device__ __forceinline__ T mass(int i) const { return m.mass(i) * ms[i * N + e]; }
-  __device__ __forceinline__ T damping(int i) const { return dm[i * N + e]; }
-  __device__ __forceinline__ T friction(int i) const { return fr[i * N + e]; }
-  __device__ __forceinline__ T mu(int i) const { return mu_[i * N + e]; }
+  static constexpr int NQ = MD::NQ;
+  __device__ __forceinline__ T mass(int i) const { return slots[(0 * NQ + i) * kWave]; }
+  __device__ __forceinline__ T damping(int i) const { return slots[(1 * NQ + i) * kWave]; }
+  __device__ __forceinline__ T friction(int i) const { return slots[(2 * NQ + i) * kWave]; }
+  __device__ __forceinline__ T mu(int i) const { return slots[(3 * NQ + i) * kWave]; }
   __device__ __forceinline__ T gravity() const { return g; }
 };
 
@@ -553,6 +550,10 @@ constexpr int kStamps = 26;   // 0..11 phases, 12..23 finer marks inside the dyn
     stamps[idx] += t_ - stamp_prev;                                                            \
     stamp_prev = t_;                                                                           \
   } while (0)
+#elif defined(OS2R_PHASE_MARKS)
+// static markers at the stamp points (diagnostic builds only: tools/phase_insts.py counts the instructions between them
+// and sets them against the stamp build's ticks): s_nop 15, then the stamp index in two s_nop immediates
+#define OS2R_STAMP(idx) asm volatile("s_nop 15\n\ts_nop %0\n\ts_nop %1" :: "i"((idx) % 8), "i"((idx) / 8) : "memory")
 #else
 #define OS2R_STAMP(idx) do { } while (0)
 #endif
@@ -641,7 +642,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   const T inv_dt = rcp_t(dt);
   // the first parameter pair of the inward pass is requested before anything else
   const T m_first = par.mass(NQ - 1), damp_first = par.damping(NQ - 1);
-  __builtin_amdgcn_sched_barrier(kPinVmem);
+  __builtin_amdgcn_sched_barrier(DR ? kPinDs : kPinVmem);
   // ---- 1. sin/cos of the joint angles; rotations are rebuilt from them where needed ----
   // The first iteration of an env-step evaluates them; the later ones turn (sin, cos) by the angle the
   // joint moved in the previous iteration, d = dt * qd (exactly the increment the integrator applied), with
@@ -731,11 +732,11 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       const T m = m_next;
       const T damp = damp_next;
       if (i > 0) {
-        // randomised parameters come from HBM/L2: request the next body's pair a whole body ahead
-        // (kPinVmem keeps the requests on this side; at one wave per SIMD nothing else hides them)
+        // randomised parameters come from their LDS slots: request the next body's pair a whole body ahead
+        // (the barrier keeps the requests on this side; at one wave per SIMD nothing else hides them)
         m_next = par.mass(i - 1);
         damp_next = par.damping(i - 1);
-        __builtin_amdgcn_sched_barrier(kPinVmem);
+        __builtin_amdgcn_sched_barrier(DR ? kPinDs : kPinVmem);
       }
       const V3<T> cm = mk(md.com(i, 0), md.com(i, 1), md.com(i, 2));
       const V3<T> h = m * cm;
@@ -944,7 +945,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   for (int j = 0; j < NQ; ++j) fb[j] = par.friction(j);
 #pragma unroll
   for (int b = 0; b < NB; ++b) mub[b] = ((CMASK >> b) & 1u) ? par.mu(b) : T(0);
-  __builtin_amdgcn_sched_barrier(kPinVmem);   // requested here, needed by the solver
+  __builtin_amdgcn_sched_barrier(DR ? kPinDs : kPinVmem);   // requested here, needed by the solver
   T y[NQ];
   T idj[NQ];  // reciprocal of Minv[j][j] = |row j of Lc|^2 (joint friction rows)
 #pragma unroll
@@ -1529,12 +1530,15 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_ISA_MARK(14);
     return cut;
   };
-  // Phase 2 with the exact finish: exact_first(NQ) sweeps, the last of them measured; from then on an environment that is
+  // Phase 2 with the exact finish: warm_first(NQ) sweeps, the last of them measured; from then on an environment that is
   // still live solves (again while a bound cuts its step short, pgs_exact solves at most per physics iteration) and
   // takes one measured sweep, until the sweep moves no more than pgs_tol or pgs_iters sweeps are spent.
   auto exact_sweeps = [&](auto first) {
     constexpr int kFirst = decltype(first)::value;
-    const int kExactFirst = first_iteration ? exact_first(NQ) : warm_first(NQ);   // (wave-uniform)
+    // (a run-time value on purpose: with a compile-time count the first sweeps are unrolled into one scheduling region whose
+    // hoisted operand reads cost the 5-dof kernels thirty registers more)
+    int kExactFirst = warm_first(NQ);
+    asm volatile("" : "+s"(kExactFirst));
     const int nfirst = pgs_iters < kExactFirst ? pgs_iters : kExactFirst;
     for (int k = 0; k + 1 < nfirst; ++k) sweep(std::false_type{}, first, std::false_type{});
     if (nfirst > 0) { moved = T(0); sweep(std::false_type{}, first, std::true_type{}); }
@@ -1590,33 +1594,35 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     if (!((CMASK >> b) & 1u)) continue;
     if (wave_act[b]) { is_suffix = is_suffix && first_act == next_cand_body<CMASK, NB>(b); first_act = b; }
   }
-  // The exact finish between its warm start (second iteration of an env-step on) and the impulses it leaves for the next.
+  // The exact finish between its warm start and the impulses it leaves for the environment's next physics iteration.
   auto exact_carried = [&](auto first) {
     constexpr int kFirst = decltype(first)::value;
-    if (!first_iteration) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (!((CMASK >> b) & 1u)) continue;
-        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-        const bool ap = ((carry.act >> b) & 1u) != 0u && dn[b] > T(0);   // a contact now and in the last iteration
-        if (__ballot(ap) == 0ull) continue;
-        const T lim = limfix[b];
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+      const bool ap = ((carry.act >> b) & 1u) != 0u && dn[b] > T(0);   // a contact now and in the last iteration
+      if (__ballot(ap) == 0ull) continue;
+      const T lim = limfix[b];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          T& l = t == 0 ? ln[b] : (t == 1 ? lx[b] : ly[b]);
-          const T prev = t == 0 ? carry.ln[b] : (t == 1 ? carry.lx[b] : carry.ly[b]);
-          T nl = t == 0 ? fmax_t(prev, T(0)) : fmin_t(fmax_t(prev, -lim), lim);
-          nl = ap ? nl : l;
-          const T dl = nl - l;
-          l = nl;
+      for (int t = 0; t < 3; ++t) {
+        T& l = t == 0 ? ln[b] : (t == 1 ? lx[b] : ly[b]);
+        const T prev = t == 0 ? carry.ln[b] : (t == 1 ? carry.lx[b] : carry.ly[b]);
+        T nl = t == 0 ? fmax_t(prev, T(0)) : fmin_t(fmax_t(prev, -lim), lim);
+        nl = ap ? nl : l;
+        const T dl = nl - l;
+        l = nl;
 #pragma unroll
-          for (int k = 0; k < NQ; ++k)
-            if (k <= b) y[k] = fma_t(Gr[b][t][k], dl, y[k]);
-        }
+        for (int k = 0; k < NQ; ++k)
+          if (k <= b) y[k] = fma_t(Gr[b][t][k], dl, y[k]);
       }
+    }
+    {
+      const bool jp = (carry.act & kCarryJoints) != 0u;   // (false in the first iteration after a reset only)
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
-        const T nl = fmin_t(fmax_t(carry.lf[j], -fb[j]), fb[j]);
+        T nl = fmin_t(fmax_t(carry.lf[j], -fb[j]), fb[j]);
+        nl = jp ? nl : lf[j];
         const T dl = nl - lf[j];
         lf[j] = nl;
 #pragma unroll
@@ -1625,7 +1631,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       }
     }
     exact_sweeps(first);
-    unsigned act = 0u;
+    unsigned act = kCarryJoints;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;

@@ -53,6 +53,22 @@ static bool layout_is(const StepArgs<T>& a) {
 template <typename MD, bool CONTACT, bool DR>
 static int launch_step(const StepArgs<T>& a, hipStream_t s) {
   const dim3 grid((unsigned)((a.N + kWave - 1) / kWave)), block(kWave);
+  // os2r_rollout (rollout_steps > 0): the fused variants -- the compiled-in robots with ground contact, the default solver
+  // settings and a reference task layout; 2 = none here, the caller steps launch by launch
+  if (a.rollout_steps > 0) {
+#if OS2R_UNIT < 10
+    if constexpr (MD::kStatic && CONTACT) {
+      if (!a.counters && is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact, MD::NQ)) {
+        constexpr int kSolver = std_solver(true, sizeof(T) == 8, StdSolver<T>::kExact);
+        if (layout_is<LayA>(a)) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, true, LayA, false, kSolver, true>), grid, block, 0, s, a); return 0; }
+#if OS2R_UNIT == 1
+        if (layout_is<LayB>(a)) { hipLaunchKernelGGL((step_kernel<T, MD, CONTACT, DR, true, LayB, false, kSolver, true>), grid, block, 0, s, a); return 0; }
+#endif
+      }
+    }
+#endif
+    return 2;
+  }
   // the compiled-in robots also exist with the default sweep counts as compile-time loop bounds
   if (MD::kStatic && is_std_solver<T>(a.pgs_iters, a.pgs_normal_iters, a.pgs_exact, MD::NQ)) {
 #if OS2R_UNIT < 10

@@ -332,17 +332,25 @@ __device__ __forceinline__ void reset_env(const StepArgs<T>& A, long long e, uin
   }
 }
 
+// Binds the per-lane parameters of one env-step: nominal ones are compile-time / scalar constants; randomised ones are
+// fetched from their HBM arrays into this lane's LDS slots (Params<.., true>), once per env-step.
 template <typename T, typename MD, bool DR>
-__device__ __forceinline__ void bind_params(const StepArgs<T>& A, long long e, const MD& md, Params<T, MD, DR>& par) {
+__device__ __forceinline__ void bind_params(const StepArgs<T>& A, long long e, const MD& md, Params<T, MD, DR>& par, T* slots) {
   par.m = md;
   if constexpr (!DR) par.g = A.gravity_z;
   if constexpr (DR) {
-    // opaque base pointers: the loads below them cannot be hoisted out of the caller's loop
-    const T* a = A.mass_scale; const T* b = A.damping; const T* c = A.friction; const T* d = A.mu;
-    asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
-    using GP = typename Params<T, MD, DR>::GP;
-    par.ms = (GP)a; par.dm = (GP)b; par.fr = (GP)c; par.mu_ = (GP)d;
-    par.N = A.N; par.e = e;
+    constexpr int NQ = MD::NQ;
+    par.g = A.gravity[e];
+    // joint by joint: four values in flight, not twenty registers held at once (this runs where the state has just been loaded)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const T ms = A.mass_scale[i * A.N + e], dm = A.damping[i * A.N + e], fr = A.friction[i * A.N + e], mu = A.mu[i * A.N + e];
+      slots[(0 * NQ + i) * kWave] = md.mass(i) * ms;
+      slots[(1 * NQ + i) * kWave] = dm;
+      slots[(2 * NQ + i) * kWave] = fr;
+      slots[(3 * NQ + i) * kWave] = mu;
+    }
+    par.slots = slots;
   }
 }
 template <typename T, int NQ>
@@ -406,8 +414,13 @@ constexpr int kWorkCounters = OS2R_NUM_WORK_COUNTERS;
 constexpr int std_solver(bool std_sweeps, bool is_f64, bool std_exact) {
   return !is_f64 ? kSolverSweeps : (std_sweeps ? (std_exact ? kSolverExact : kSolverSweeps) : kSolverBoth);
 }
+// ROLLOUT: A.rollout_steps env-steps in this launch (os2r_rollout): every wave advances its own 64 environments step
+// after step -- no device-wide barrier between the env-steps, where one launch per env-step makes 1024 waves wait for
+// the slowest -- with the state in registers from the first step to the last; step k writes its observation, reward,
+// done flag (terminal observation, done reason) at offset k of the [K][N]... output arrays and takes its actions from
+// slice k of the [K][N][2] input (or draws them with the step counter + k).  The arithmetic of a step is the same code.
 template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS = false, typename LAY = RtLayout, bool COUNT = false,
-          int SOLVER = std_solver(STD_SWEEPS, sizeof(T) == 8, StdSolver<T>::kExact)>
+          int SOLVER = std_solver(STD_SWEEPS, sizeof(T) == 8, StdSolver<T>::kExact), bool ROLLOUT = false>
 __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   constexpr int NQ = MD::NQ;
   // run-time models scan a wave-shared LDS copy of the candidate table; the compiled-in ones read the
@@ -417,77 +430,192 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   const unsigned long long stamp_entry = __builtin_amdgcn_s_memtime();
   const unsigned long long real_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-  __shared__ T tile[lds_words<NQ>() + (kCandInLds ? kCandWords : 0)];
+  // [per-lane slots of the physics iteration | per-lane parameter slots (DR) | wave-shared candidate table (run-time models)]
+  constexpr int kParamWords = DR ? 4 * NQ * kWave : 0;
+  __shared__ T tile[lds_words<NQ>() + kParamWords + (kCandInLds ? kCandWords : 0)];
   const int lane = threadIdx.x;
   const long long e0 = (long long)blockIdx.x * kWave;
   const bool valid = e0 + lane < A.N;
-  const long long e = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
+  const long long e_lane = valid ? e0 + lane : A.N - 1;  // tail lanes shadow the last env, stores are masked
   const MD md = make_model<T, MD>(A);
-  T* cand_lds = tile + lds_words<NQ>();
+  T* cand_lds = tile + lds_words<NQ>() + kParamWords;
   if constexpr (kCandInLds) {
     const int nc3 = 3 * md.cand_begin(NQ);
     for (int k = lane; k < nc3; k += kWave) cand_lds[k] = md.cand(k / 3, k % 3);
     __syncthreads();
   }
-  const TaskPtr<T> ts = as_const(A.task);
-
-  T q[NQ], qd[NQ];
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) {
-    q[i] = A.q[i * A.N + e];
-    qd[i] = A.qd[i * A.N + e];
-  }
-  Params<T, MD, DR> par;
-  bind_params<T, MD, DR>(A, e, md, par);
-  if constexpr (DR) par.g = A.gravity[e];
-
-  // action: caller-provided or drawn from the counter RNG (stream 1, counter = step count)
-  T ax, ay;
-  if (A.actions) {
-    ax = A.actions[2 * e];
-    ay = A.actions[2 * e + 1];
-    const bool outside = ax < T(-1) || ax > T(1) || ay < T(-1) || ay > T(1);
-    if (__ballot(outside) != 0ull && outside && A.violations) atomicAdd(A.violations, 1u);
-  } else {
-    double u0, u1;
-    uniform2(A.seed, (uint32_t)(A.env_offset + e), kStreamAction, (uint32_t)A.step_count,
-             (uint32_t)(A.step_count >> 32), u0, u1);
-    ax = (T)(2.0 * u0 - 1.0);
-    ay = (T)(2.0 * u1 - 1.0);
-  }
-  ax = ax < T(-1) ? T(-1) : (ax > T(1) ? T(1) : ax);
-  ay = ay < T(-1) ? T(-1) : (ay > T(1) ? T(1) : ay);
-  T tau_hip, tau_knee, asx, asy;
-  {
-#pragma clang fp contract(off)
-    tau_hip = md.max_torque(0) * ax;    // tasks/monopod.py:223
-    tau_knee = md.max_torque(1) * ay;
-    asx = tau_hip / md.max_torque(0);   // what action_history stores (:233-235)
-    asy = tau_knee / md.max_torque(1);
-  }
-
+  const TaskPtr<T> ts_launch = as_const(A.task);
+  const int D = LAY::kStatic ? LAY::kDim : ts_launch->obs_dim;
 #ifdef OS2R_STAMPS
   unsigned long long stamps[kStamps] = {}, stamp_prev = __builtin_amdgcn_s_memtime();
   stamps[10] = stamp_prev - stamp_entry;   // prologue: loads, action, torques
 #endif
   T sn[NQ], cs[NQ];   // sin/cos of the joint angles, carried from one physics iteration to the next
   WorkCounts wc;
-  SolverCarry<T, NQ> carry;   // what the exact finish hands from one physics iteration to the next (os2r_device.hpp)
-  for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
-    if constexpr (DR) bind_params<T, MD, DR>(A, e, md, par);
-    substep<T, MD, CONTACT, DR, COUNT, SOLVER>(
-                                       md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
-                                       STD_SWEEPS ? std_iters<T>(NQ) : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
-                                       A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc, carry
+  const int nsteps = ROLLOUT ? A.rollout_steps : 1;
+  for (int k = 0; k < nsteps; ++k) {
+    const long long ko = ROLLOUT ? (long long)k * A.N : 0ll;   // this step's slice of the output arrays
+    // (a rollout passes the state from one env-step to the next through memory like separate launches do -- its own
+    // lines, L2-resident: held in registers across the epilogue it costs the 5-dof kernels 140-390 B of scratch per lane --
+    // and its environment index is a fresh value in every step: otherwise the address of every state array, sixty of
+    // them, is hoisted out of the step loop and held in registers across it: 450 B of scratch)
+    long long e = e_lane;
+    if constexpr (ROLLOUT) asm volatile("" : "+v"(e));
+    TaskPtr<T> ts = ts_launch;   // (and the task's constants are fetched where they are used, step by step)
+    if constexpr (ROLLOUT) asm volatile("" : "+s"(ts));
+    T q[NQ], qd[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      q[i] = A.q[i * A.N + e];
+      qd[i] = A.qd[i * A.N + e];
+    }
+    Params<T, MD, DR> par;
+    bind_params<T, MD, DR>(A, e, md, par, tile + lds_words<NQ>() + lane);
+
+    // what the exact finish hands from one physics iteration to the next (os2r_device.hpp): part of the environment's state
+    constexpr bool kCarry = sizeof(T) == 8 && SOLVER != kSolverSweeps;
+    SolverCarry<T, NQ> carry;
+    if constexpr (kCarry) {
+      carry.act = A.solver_flags[e];
+#pragma unroll
+      for (int b = 0; b < NQ; ++b) {
+        if (CONTACT && ((MD::CMASK >> b) & 1u)) {
+          carry.ln[b] = A.solver_l[(0 * NQ + b) * A.N + e];
+          carry.lx[b] = A.solver_l[(1 * NQ + b) * A.N + e];
+          carry.ly[b] = A.solver_l[(2 * NQ + b) * A.N + e];
+        }
+        carry.lf[b] = A.solver_l[(3 * NQ + b) * A.N + e];
+      }
+    }
+    const unsigned long long step_count = A.step_count + (unsigned long long)k;
+    // action: caller-provided or drawn from the counter RNG (stream 1, counter = step count)
+    T ax, ay;
+    if (A.actions) {
+      ax = A.actions[2 * (ko + e)];
+      ay = A.actions[2 * (ko + e) + 1];
+      const bool outside = ax < T(-1) || ax > T(1) || ay < T(-1) || ay > T(1);
+      if (__ballot(outside) != 0ull && outside && A.violations) atomicAdd(A.violations, 1u);
+    } else {
+      double u0, u1;
+      uniform2(A.seed, (uint32_t)(A.env_offset + e), kStreamAction, (uint32_t)step_count, (uint32_t)(step_count >> 32), u0, u1);
+      ax = (T)(2.0 * u0 - 1.0);
+      ay = (T)(2.0 * u1 - 1.0);
+    }
+    ax = ax < T(-1) ? T(-1) : (ax > T(1) ? T(1) : ax);
+    ay = ay < T(-1) ? T(-1) : (ay > T(1) ? T(1) : ay);
+    T tau_hip, tau_knee, asx, asy;
+    {
+#pragma clang fp contract(off)
+      tau_hip = md.max_torque(0) * ax;    // tasks/monopod.py:223
+      tau_knee = md.max_torque(1) * ay;
+      asx = tau_hip / md.max_torque(0);   // what action_history stores (:233-235)
+      asy = tau_knee / md.max_torque(1);
+    }
+
+    for (int s = 0; s < A.substeps; ++s) {  // runtimes/gazebo_runtime.py:70-77
+      substep<T, MD, CONTACT, DR, COUNT, SOLVER>(
+                                         md, par, q, qd, sn, cs, s == 0, tau_hip, tau_knee, A.dt, A.erp, A.max_erv, A.margin,
+                                         STD_SWEEPS ? std_iters<T>(NQ) : A.pgs_iters, STD_SWEEPS ? StdSolver<T>::kNormalIters : A.pgs_normal_iters,
+                                         A.pgs_exact, A.pgs_tol, tile, cand_lds, as_const(A.model), wc, carry
 #ifdef OS2R_STAMPS
-                                       , stamps, stamp_prev
+                                         , stamps, stamp_prev
 #endif
-    );
+      );
+    }
+    __syncthreads();
+    // The contact solver's state goes back to HBM here, straight after the last physics iteration: held until the end of
+    // the env-step it would be live across the whole epilogue -- forty registers more at the kernel's widest point.
+    if constexpr (kCarry) {
+      if (valid) {
+        A.solver_flags[e] = carry.act;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+          // (an impulse that is not remembered is stored as zero: the arrays are a function of the trajectory alone)
+          const bool cb = ((carry.act >> b) & 1u) != 0u;
+          A.solver_l[(0 * NQ + b) * A.N + e] = cb ? carry.ln[b] : T(0);
+          A.solver_l[(1 * NQ + b) * A.N + e] = cb ? carry.lx[b] : T(0);
+          A.solver_l[(2 * NQ + b) * A.N + e] = cb ? carry.ly[b] : T(0);
+          A.solver_l[(3 * NQ + b) * A.N + e] = carry.lf[b];
+        }
+      }
+    }
+
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) bad = bad || !finite_t(q[i]) || !finite_t(qd[i]) || fabs_t(q[i]) > T(1e30) || fabs_t(qd[i]) > T(1e30);
+
+    // (the bookkeeping of an environment -- action history, step and episode counters -- is fetched where it is used and
+    // stored at the end of every env-step, in a rollout as well: nothing of it is held across the physics iterations)
+    const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
+    T obs[OS2R_MAX_OBS];
+    bool dn;
+    unsigned why;
+    OS2R_STAMP(20);
+    observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn, why);
+    OS2R_STAMP(21);
+    const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
+    OS2R_STAMP(22);
+    int steps = A.steps[e] + 1;
+    const bool trunc = ts->max_episode_steps > 0 && steps >= ts->max_episode_steps;
+    const uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
+
+    if (A.term_obs) store_obs_tile<T>(A.term_obs + ko * D, obs, D, e0, A.N, lane, tile);
+
+    uint32_t epi = A.episode[e];
+    uint8_t pose = A.pose[e];
+    const bool do_reset = flag != 0 && A.auto_reset != 0;
+    ParamVals<T, NQ> pv;
+    if (__ballot(do_reset) != 0ull) {
+      if (do_reset) {
+        reset_env<T, MD, DR>(A, e, epi, q, qd, pv, pose);
+        epi += 1;
+        steps = 0;
+        bool dn2;
+        unsigned why2;
+        observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn2, why2);
+        // a new episode: the contact solver remembers nothing
+        if constexpr (kCarry) {
+          if (valid) {
+            A.solver_flags[e] = 0u;
+#pragma unroll
+            for (int k = 0; k < 4 * NQ; ++k) A.solver_l[k * A.N + e] = T(0);
+          }
+        }
+      }
+    }
+    if (A.obs) store_obs_tile<T>(A.obs + ko * D, obs, D, e0, A.N, lane, tile);
+    OS2R_STAMP(23);
+    if (valid) {
+      A.hist[2 * A.N + e] = h1x;
+      A.hist[3 * A.N + e] = h1y;
+      A.hist[0 * A.N + e] = asx;
+      A.hist[1 * A.N + e] = asy;
+      A.steps[e] = steps;
+      if (do_reset) {
+        A.episode[e] = epi;
+        A.pose[e] = pose;
+        store_params<T, NQ>(A, e, pv);
+      }
+      if (A.reward) A.reward[ko + e] = rew;
+      if (A.done) A.done[ko + e] = flag;
+      if (A.reason) A.reason[ko + e] = (uint16_t)why;
+    }
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        A.q[i * A.N + e] = q[i];
+        A.qd[i * A.N + e] = qd[i];
+      }
+    }
+    if constexpr (ROLLOUT) {
+      // the next step of this lane reads what this one has just written: same lane, same addresses, program order (vector
+      // memory operations of a wave are performed in order); the compiler is kept from moving those loads up
+      asm volatile("" ::: "memory");
+    }
   }
-  __syncthreads();
   if constexpr (COUNT) {
     if (A.counters && lane == 0) {
-      const unsigned long long v[kWorkCounters] = {(unsigned long long)A.substeps, wc.scanned, wc.row_bodies, wc.body_sweeps,
+      const unsigned long long v[kWorkCounters] = {(unsigned long long)A.substeps * (unsigned long long)nsteps, wc.scanned, wc.row_bodies, wc.body_sweeps,
                                                     wc.sweeps, wc.lane_contacts, wc.live_lane_sweeps, wc.full_sincos,
                                                     wc.exact_solves, wc.lane_exact_solves};
 #pragma unroll
@@ -495,63 +623,6 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     }
   }
 
-  bool bad = false;
-#pragma unroll
-  for (int i = 0; i < NQ; ++i) bad = bad || !finite_t(q[i]) || !finite_t(qd[i]) || fabs_t(q[i]) > T(1e30) || fabs_t(qd[i]) > T(1e30);
-
-  const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
-  T obs[OS2R_MAX_OBS];
-  bool dn;
-  unsigned why;
-  OS2R_STAMP(20);
-  observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn, why);
-  OS2R_STAMP(21);
-  const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
-  OS2R_STAMP(22);
-  int steps = A.steps[e] + 1;
-  const bool trunc = ts->max_episode_steps > 0 && steps >= ts->max_episode_steps;
-  const uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
-  const int D = LAY::kStatic ? LAY::kDim : ts->obs_dim;
-
-  if (A.term_obs) store_obs_tile<T>(A.term_obs, obs, D, e0, A.N, lane, tile);
-
-  uint32_t epi = A.episode[e];
-  uint8_t pose = A.pose[e];
-  const bool do_reset = flag != 0 && A.auto_reset != 0;
-  ParamVals<T, NQ> pv;
-  if (__ballot(do_reset) != 0ull) {
-    if (do_reset) {
-      reset_env<T, MD, DR>(A, e, epi, q, qd, pv, pose);
-      epi += 1;
-      steps = 0;
-      bool dn2;
-      unsigned why2;
-      observe<T, NQ, LAY>(ts, q, qd, h1x, h1y, obs, dn2, why2);
-    }
-  }
-  if (A.obs) store_obs_tile<T>(A.obs, obs, D, e0, A.N, lane, tile);
-  OS2R_STAMP(23);
-
-  if (valid) {
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      A.q[i * A.N + e] = q[i];
-      A.qd[i * A.N + e] = qd[i];
-    }
-    A.hist[2 * A.N + e] = h1x;
-    A.hist[3 * A.N + e] = h1y;
-    A.hist[0 * A.N + e] = asx;
-    A.hist[1 * A.N + e] = asy;
-    A.steps[e] = steps;
-    if (do_reset) {
-      A.episode[e] = epi;
-      A.pose[e] = pose;
-      store_params<T, NQ>(A, e, pv);
-    }
-    if (A.reward) A.reward[e] = rew;
-    if (A.done) A.done[e] = flag;
-    if (A.reason) A.reason[e] = (uint16_t)why;
-  }
 #ifdef OS2R_STAMPS
   stamps[11] = __builtin_amdgcn_s_memtime() - stamp_prev;   // the state and flag stores, issued
   // the wave's life in shader-clock ticks and in ticks of the constant 100 MHz counter: their quotient is the clock
@@ -572,9 +643,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   __launch_bounds__(os2r::kWave) __attribute__((amdgpu_waves_per_eu(sizeof(REAL) == 4 ? 2 : 1)))
 
 template <typename T, typename MD, bool CONTACT, bool DR, bool STD_SWEEPS, typename LAY = RtLayout, bool COUNT = false,
-          int SOLVER = std_solver(STD_SWEEPS, sizeof(T) == 8, StdSolver<T>::kExact)>
+          int SOLVER = std_solver(STD_SWEEPS, sizeof(T) == 8, StdSolver<T>::kExact), bool ROLLOUT = false>
 __global__ OS2R_STEP_KERNEL_ATTRS(T) void step_kernel(const StepArgs<T> A) {
-  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY, COUNT, SOLVER>(A);
+  step_body<T, MD, CONTACT, DR, STD_SWEEPS, LAY, COUNT, SOLVER, ROLLOUT>(A);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -619,6 +690,9 @@ __global__ __launch_bounds__(kWave) void reset_kernel(const StepArgs<T> A) {
     A.pose[e] = pose;
     A.steps[e] = 0;
     store_params<T, NQ>(A, e, pv);
+    A.solver_flags[e] = 0u;   // a new episode: the contact solver remembers nothing
+#pragma unroll
+    for (int k = 0; k < 4 * NQ; ++k) A.solver_l[k * A.N + e] = T(0);
   }
 }
 

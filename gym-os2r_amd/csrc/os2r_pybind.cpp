@@ -30,6 +30,10 @@ PYBIND11_MODULE(_os2r_py, m) {
   m.def("reset", [](addr h, addr mask, addr obs, addr st) { return os2r_reset(H(h), (const uint8_t*)P(mask), P(obs), P(st)); }, nogil);
   m.def("step", [](addr h, addr act, addr obs, addr rew, addr done, addr term, addr st) {
     return os2r_step(H(h), P(act), P(obs), P(rew), (uint8_t*)P(done), P(term), P(st)); }, nogil);
+  m.def("rollout", [](addr h, int n, addr act, addr obs, addr rew, addr done, addr term, addr why, addr st) {
+    return os2r_rollout(H(h), n, P(act), P(obs), P(rew), (uint8_t*)P(done), P(term), (uint16_t*)P(why), P(st)); }, nogil);
+  m.def("get_solver_state", [](addr h, addr l, addr f, addr st) { return os2r_get_solver_state(H(h), P(l), (uint32_t*)P(f), P(st)); }, nogil);
+  m.def("set_solver_state", [](addr h, addr l, addr f, addr st) { return os2r_set_solver_state(H(h), P(l), (const uint32_t*)P(f), P(st)); }, nogil);
   m.def("get_state", [](addr h, addr q, addr qd, addr st) { return os2r_get_state(H(h), P(q), P(qd), P(st)); }, nogil);
   m.def("set_state", [](addr h, addr q, addr qd, addr st) { return os2r_set_state(H(h), P(q), P(qd), P(st)); }, nogil);
   m.def("get_action_history", [](addr h, int w, addr o, addr st) { return os2r_get_action_history(H(h), w, P(o), P(st)); }, nogil);

@@ -39,25 +39,82 @@ def make_sharded(env_id: str, total_envs: int, seed: int = 0, randomizer=None, *
     return randomizer(env=factory) if randomizer is not None else factory()
 
 
-def gather_to_rank0(tensor, total_envs: int, dst: int = 0):
-    """Concatenate per-rank [n_r, ...] tensors on rank ``dst`` in global env order (None elsewhere).
+class Rank0Gather:
+    """Gathers per-rank [n_r, ...] tensors into ONE preallocated [total_envs, ...] tensor on rank ``dst``, in global env
+    order -- what replaces the ``np.stack`` of the workers' results on the parent process in the reference
+    (common/vec_env/subproc_vec_env.py:119-123).
 
-    Uses ``torch.distributed.gather`` on the initialised process group: RCCL over xGMI for CUDA
-    tensors ("nccl" backend), gloo for CPU tensors.  Shards may differ by one row; they are padded
-    to the largest shard for the collective and trimmed afterwards.
+    Nothing is allocated or concatenated per call: rank ``dst`` owns the output (one per ``key``: obs / reward / done ...,
+    or the caller's own ``out=``) and the collective -- ``torch.distributed.gather``: RCCL sends and receives over xGMI for
+    CUDA tensors ("nccl" backend), gloo for CPU tensors -- writes every rank's rows straight into their slice of it.
+    Shards that differ by one row (``shard_range``) go through a preallocated padded staging block, because the collective
+    wants equal sizes, and are copied slice by slice from there.  Works with a single rank too (the collective runs; the
+    one-GPU rehearsal of the multi-rank path depends on that).  Stream-ordered on the current stream, as the collective is.
     """
-    import torch
+
+    def __init__(self, total_envs: int, dst: int = 0):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("Rank0Gather needs an initialised process group")
+        self.dst, self.total = int(dst), int(total_envs)
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        parts = [shard_range(self.total, r, self.world) for r in range(self.world)]
+        self.offsets, self.counts = [p[0] for p in parts], [p[1] for p in parts]
+        self.nmax = max(self.counts)
+        self.even = min(self.counts) == self.nmax
+        self._out, self._stage, self._pad = {}, {}, {}
+
+    def _like(self, tensor, rows):
+        import torch
+        return torch.empty((rows,) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+
+    def __call__(self, tensor, key="x", out=None):
+        """-> the gathered [total_envs, ...] tensor on rank ``dst`` (the same storage every call unless ``out`` is given), None elsewhere."""
+        import torch.distributed as dist
+        if tensor.shape[0] != self.counts[self.rank]:
+            raise ValueError(f"rank {self.rank} owns {self.counts[self.rank]} environments, got {tensor.shape[0]} rows")
+        tensor = tensor.contiguous()
+        sig = (key, tuple(tensor.shape[1:]), tensor.dtype, tensor.device)
+        on_dst = self.rank == self.dst
+        if on_dst and out is None:
+            out = self._out.get(sig)
+            if out is None:
+                out = self._out[sig] = self._like(tensor, self.total)
+        if self.even:
+            views = [out[o:o + c] for o, c in zip(self.offsets, self.counts)] if on_dst else None
+            dist.gather(tensor, views, dst=self.dst)
+            return out if on_dst else None
+        send = tensor
+        if tensor.shape[0] < self.nmax:                # (one row short: padded in a block that is allocated once)
+            send = self._pad.get(sig)
+            if send is None:
+                send = self._pad[sig] = self._like(tensor, self.nmax).zero_()
+            send[:tensor.shape[0]].copy_(tensor)
+        stage = None
+        if on_dst:
+            stage = self._stage.get(sig)
+            if stage is None:
+                stage = self._stage[sig] = self._like(tensor, self.world * self.nmax)
+        dist.gather(send, [stage[r * self.nmax:(r + 1) * self.nmax] for r in range(self.world)] if on_dst else None, dst=self.dst)
+        if not on_dst:
+            return None
+        for r, (o, c) in enumerate(zip(self.offsets, self.counts)):
+            out[o:o + c].copy_(stage[r * self.nmax:r * self.nmax + c])
+        return out
+
+
+_gatherers = {}
+
+
+def gather_to_rank0(tensor, total_envs: int, dst: int = 0, key="x", out=None):
+    """Per-rank [n_r, ...] tensors -> one [total_envs, ...] tensor on rank ``dst`` in global env order (None elsewhere):
+    ``Rank0Gather`` with one cached instance per (total_envs, dst).  The result on rank ``dst`` is the gatherer's own
+    buffer for ``key`` -- overwritten by the next gather with the same key, shape and dtype -- unless ``out`` is given.
+    Without a process group the tensor is returned as it is."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return tensor
-    world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [shard_range(total_envs, r, world)[1] for r in range(world)]
-    nmax = max(counts)
-    pad = tensor
-    if tensor.shape[0] < nmax:
-        pad = torch.cat([tensor, tensor.new_zeros((nmax - tensor.shape[0],) + tuple(tensor.shape[1:]))])
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad.contiguous(), bufs, dst=dst)
-    if rank != dst:
-        return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)])
+    g = _gatherers.get((int(total_envs), int(dst), dist.get_world_size()))
+    if g is None:
+        g = _gatherers[(int(total_envs), int(dst), dist.get_world_size())] = Rank0Gather(total_envs, dst)
+    return g(tensor, key=key, out=out)

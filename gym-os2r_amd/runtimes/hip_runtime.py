@@ -227,7 +227,10 @@ class HipRuntime:
         lazy = {"reset_orientation_id": lambda: sim.episode_info()[2],
                 "truncated": lambda: (flags & abi.TRUNCATED_BIT).bool()}
         if sim.reasons is not None:
-            lazy["done_reason"] = lambda: sim.reasons.clone()      # bit d: observation d left the reset space
+            # a copy of this step's reasons, made now on the launching stream (2 bytes per environment): the handle's buffer is
+            # rewritten by the next step, and a getter evaluated later would report that step's
+            why = sim.reasons.clone()
+            lazy["done_reason"] = lambda: why                      # bit d: observation d left the reset space
         info = BatchedInfo(done_flags=flags, terminal_observation=term, lazy=lazy)
         return obs, rew, flags != 0, info
 

@@ -54,6 +54,16 @@ class _PybindLib:
     def os2r_set_state(self, h, q, qd, st):
         return self.m.set_state(self._a(h), self._a(q), self._a(qd), self._a(st))
 
+    def os2r_get_solver_state(self, h, lam, flags, st):
+        return self.m.get_solver_state(self._a(h), self._a(lam), self._a(flags), self._a(st))
+
+    def os2r_set_solver_state(self, h, lam, flags, st):
+        return self.m.set_solver_state(self._a(h), self._a(lam), self._a(flags), self._a(st))
+
+    def os2r_rollout(self, h, n, act, obs, rew, done, term, reason, st):
+        return self.m.rollout(self._a(h), int(n), self._a(act), self._a(obs), self._a(rew), self._a(done), self._a(term),
+                              self._a(reason), self._a(st))
+
     def os2r_get_action_history(self, h, w, o, st):
         return self.m.get_action_history(self._a(h), int(w), self._a(o), self._a(st))
 
@@ -179,6 +189,25 @@ class HipSim:
         self._check(self._lib.os2r_step(self._h, _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term),
                                         self._stream()), "os2r_step")
 
+    def rollout(self, nsteps: int, actions=None, want_terminal: bool = False, want_reasons: bool = False):
+        """`nsteps` env-steps in one call (include/os2r.h: os2r_rollout; one launch where a fused kernel exists): open-loop
+        actions [K,N,2] or None (on-device random actions).  -> obs [K,N,D], reward [K,N], done [K,N] uint8 flags,
+        terminal_obs [K,N,D] or None, reasons [K,N] int16 or None -- what K calls of step() return, bit for bit."""
+        K = int(nsteps)
+        a = None if actions is None else self._in(actions, (K, self.N, 2))
+        obs, rew = self._new(K, self.N, self.D), self._new(K, self.N)
+        done = self._new(K, self.N, dtype=torch.uint8)
+        term = self._new(K, self.N, self.D) if want_terminal else None
+        why = self._new(K, self.N, dtype=torch.int16) if want_reasons else None
+        self._check(self._lib.os2r_rollout(self._h, K, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term), _ptr(why),
+                                           self._stream()), "os2r_rollout")
+        return obs, rew, done, term, why
+
+    def rollout_into(self, nsteps: int, actions, obs, rew, done, term=None, reasons=None):
+        """Allocation-free variant of rollout() writing into caller tensors ([K,N,...])."""
+        self._check(self._lib.os2r_rollout(self._h, int(nsteps), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term),
+                                           _ptr(reasons), self._stream()), "os2r_rollout")
+
     def reset(self, mask: Optional[torch.Tensor] = None):
         m = None if mask is None else self._in(mask, (self.N,), torch.uint8)
         obs = self._new(self.N, self.D)
@@ -252,6 +281,22 @@ class HipSim:
         self._check(self._lib.os2r_set_state(self._h, _ptr(q), _ptr(qd), self._stream()), "os2r_set_state")
         torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
 
+    def get_solver_state(self):
+        """(lambda [4*nq, N], flags [N] int32 holding the uint32 payload): the impulses that ended every environment's last
+        physics iteration and which of them are remembered (include/os2r.h: os2r_get_solver_state)."""
+        lam, flags = self._new(4 * self.nq, self.N), self._new(self.N, dtype=torch.int32)
+        self._check(self._lib.os2r_get_solver_state(self._h, _ptr(lam), _ptr(flags), self._stream()), "os2r_get_solver_state")
+        return lam, flags
+
+    def set_solver_state(self, lam, flags):
+        lam = self._in(lam, (4 * self.nq, self.N))
+        if not isinstance(flags, torch.Tensor):
+            import numpy as np
+            flags = torch.from_numpy(np.ascontiguousarray(flags).astype(np.uint32).view(np.int32))
+        flags = self._in(flags, (self.N,), torch.int32)
+        self._check(self._lib.os2r_set_solver_state(self._h, _ptr(lam), _ptr(flags), self._stream()), "os2r_set_solver_state")
+        torch.cuda.current_stream(self.device).synchronize()  # inputs may be temporaries
+
     def get_action_history(self, which: int):
         out = self._new(2, self.N)
         self._check(self._lib.os2r_get_action_history(self._h, int(which), _ptr(out), self._stream()),
@@ -294,7 +339,8 @@ class HipSim:
         """Everything that determines the future of this handle, as device tensors (+ the step counter)."""
         q, qd = self.get_state()
         steps, episode, pose = self.episode_info()
-        return {"q": q, "qd": qd, "hist0": self.get_action_history(0), "hist1": self.get_action_history(1),
+        lam, flags = self.get_solver_state()
+        return {"q": q, "qd": qd, "solver_lambda": lam, "solver_flags": flags, "hist0": self.get_action_history(0), "hist1": self.get_action_history(1),
                 "params": {f: self.get_params(f) for f in (abi.PARAM_MASS_SCALE, abi.PARAM_DAMPING, abi.PARAM_FRICTION,
                                                             abi.PARAM_MU, abi.PARAM_GRAVITY)},
                 "steps": steps, "episode": episode, "pose": pose, "step_count": self.step_count}
@@ -302,6 +348,7 @@ class HipSim:
     def restore(self, ck: dict):
         """Continue from a `checkpoint()` (of this or of another handle with the same configuration)."""
         self.set_state(ck["q"], ck["qd"])
+        self.set_solver_state(ck["solver_lambda"], ck["solver_flags"])   # (after set_state, which clears it)
         self.set_action_history(0, ck["hist0"]); self.set_action_history(1, ck["hist1"])
         for f, v in ck["params"].items():
             self.set_params(f, v)

@@ -32,7 +32,14 @@
 extern "C" {
 #endif
 
-#define OS2R_ABI_VERSION 3
+/* The library is built with -fvisibility=hidden: the entry points declared here are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#define OS2R_API __attribute__((visibility("default")))
+#else
+#define OS2R_API
+#endif
+
+#define OS2R_ABI_VERSION 4
 
 #define OS2R_MAX_DOF 5      /* yaw, pitch, boom_connector, hip, knee                       */
 #define OS2R_MAX_CAND 192   /* ground-contact candidate points of one model                */
@@ -168,9 +175,9 @@ typedef struct Os2rConfig {
   double pgs_tol;          /* an environment stops sweeping once a checked sweep moved no more     */
                            /*   energy than this [J]; 0: exact fixed points only                   */
   int32_t pgs_exact;       /* exact finish of the boxed LCP: an environment that   */
-                           /*   has not converged after the first sweeps of phase 2 (6 in the first  */
-                           /*   iteration of a step, 4 for robots with fewer than five dof; 3 in    */
-                           /*   the later ones, which start from the previous impulses) solves its  */
+                           /*   has not converged after the first three sweeps of phase 2 (which    */
+                           /*   starts from the impulses of the environment's previous iteration,   */
+                           /*   os2r_get_solver_state) solves its                                   */
                            /*   free rows exactly (a 5x5 system in the whitened velocities), with  */
                            /*   active-set pivots (a step cut at a bound; an inconsistent free set */
                            /*   left by a step to the first bound), at most this many solves per   */
@@ -194,18 +201,18 @@ enum {
 
 typedef struct Os2rSim Os2rSim;
 
-int os2r_abi_version(void);
+OS2R_API int os2r_abi_version(void);
 
 /* Allocates device state for cfg->num_envs environments, initialises per-env
  * parameters to the model's nominal values (gravity: N(mean,std) per env when
  * task.reset_mode==OS2R_RESET_RANDOM) and performs a full reset. */
-int os2r_create(const Os2rConfig* cfg, Os2rSim** out);
-int os2r_destroy(Os2rSim* sim);
+OS2R_API int os2r_create(const Os2rConfig* cfg, Os2rSim** out);
+OS2R_API int os2r_destroy(Os2rSim* sim);
 
 /* Reset the environments whose mask byte is non-zero (mask_dev == NULL: all).
  * Replaces GazeboEnvRandomizer.reset -> randomize_task -> task.reset_task.
  * obs_dev (nullable) receives the [num_envs, obs_dim] observation of every env. */
-int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* stream);
+OS2R_API int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* stream);
 
 /* One env-step for every environment: `substeps` physics iterations with the
  * action held, then observation, reward, done; done environments are reset in
@@ -218,8 +225,21 @@ int os2r_reset(Os2rSim* sim, const uint8_t* mask_dev, void* obs_dev, void* strea
  *                                     bit2 non-finite state guard
  *   term_obs_dev [num_envs,obs_dim]   nullable; observation before auto-reset
  *                                     (info['terminal_observation'])            */
-int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev,
+OS2R_API int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward_dev,
               uint8_t* done_dev, void* term_obs_dev, void* stream);
+
+/* `nsteps` env-steps of every environment, as `nsteps` calls of os2r_step would make them -- bit for bit -- but without a
+ * device-wide barrier between the env-steps: where a fused variant of the step kernel exists (the compiled-in robots
+ * with ground contact, the default solver settings and a reference task layout) the whole rollout is ONE launch in which
+ * every wave advances its own 64 environments step after step, state in registers; otherwise the library makes the
+ * `nsteps` launches itself.  For open-loop action sequences and random rollouts (the reference's workers advance
+ * independently of each other: gym_os2r/common/vec_env/subproc_vec_env.py:15-21); a policy in the loop needs os2r_step.
+ *   actions_dev  [nsteps][num_envs][2] or NULL (on-device U(-1,1) actions, step counter as in os2r_step)
+ *   obs_dev      [nsteps][num_envs][obs_dim], reward_dev [nsteps][num_envs], done_dev [nsteps][num_envs] uint8,
+ *   term_obs_dev [nsteps][num_envs][obs_dim] (nullable), reason_dev [nsteps][num_envs] uint16 (nullable; the done
+ *                reasons of os2r_set_done_reasons per step -- the buffer set there is not written by a rollout)  */
+OS2R_API int os2r_rollout(Os2rSim* sim, int nsteps, const void* actions_dev, void* obs_dev, void* reward_dev,
+                          uint8_t* done_dev, void* term_obs_dev, uint16_t* reason_dev, void* stream);
 
 /* Model-specialised kernels.  A robot that is not one of the four compiled-in reference variants
  * runs on generic kernels that read its constants through scalar loads (about half the speed).
@@ -234,8 +254,8 @@ int os2r_step(Os2rSim* sim, const void* actions_dev, void* obs_dev, void* reward
  * kernels with that observation layout folded in; handles whose task has exactly that layout use
  * them, and of several code objects of one robot the one built for the handle's layout is taken.
  * Errors: os2r_last_error(NULL).                                                            */
-int os2r_model_is_compiled_in(const Os2rModel* model);
-int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t device,
+OS2R_API int os2r_model_is_compiled_in(const Os2rModel* model);
+OS2R_API int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t device,
                                 const char* code_object_path);
 
 /* Caller-provided actions outside [-1, 1]: the reference asserts on them in Python
@@ -243,34 +263,47 @@ int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, int32_t d
  * (tasks/monopod.py:313-316).  The kernel clamps and counts them; this copies the running count
  * of offending environments to dst (device or pinned host memory, ordered on the stream, so a
  * host binding can look at it one call later without stalling) and clears it if `clear`.   */
-int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void* stream);
+OS2R_API int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void* stream);
 
-/* State access in chain dof order, SoA [nq][num_envs], handle's dtype. */
-int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream);
-int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* stream);
+/* State access in chain dof order, SoA [nq][num_envs], handle's dtype.  os2r_set_state also clears the contact
+ * solver's state (below): a state set from outside starts like a reset.                                     */
+OS2R_API int os2r_get_state(Os2rSim* sim, void* q_dev, void* qd_dev, void* stream);
+OS2R_API int os2r_set_state(Os2rSim* sim, const void* q_dev, const void* qd_dev, void* stream);
+
+/* The contact solver's state (fp64 handles with the exact finish; carried but unused otherwise).  The reference's
+ * backend keeps one persistent constraint solver per world (behind gym_os2r/runtimes/gazebo_runtime.py:76,111-114);
+ * here every environment remembers the impulses that ended its last physics iteration, and the next one -- of the same
+ * env-step or of the next -- starts its contact solve from them.  A reset clears it.
+ *   lambda_dev [4*nq][num_envs], handle's dtype: rows b, nq + b, 2nq + b: normal and the two tangential (world x, y)
+ *              impulses of body b's ground contact; row 3nq + j: Coulomb friction impulse of joint j
+ *   flags_dev  [num_envs] uint32: bit b: body b had a contact (its three impulses are remembered); bit 31: an iteration
+ *              has run since the reset (the joint impulses are remembered)
+ * Part of a checkpoint: restore it after os2r_set_state.  get: either pointer may be NULL.                        */
+OS2R_API int os2r_get_solver_state(Os2rSim* sim, void* lambda_dev, uint32_t* flags_dev, void* stream);
+OS2R_API int os2r_set_solver_state(Os2rSim* sim, const void* lambda_dev, const uint32_t* flags_dev, void* stream);
 
 /* Action history: [2][num_envs] SoA; which=0 last applied action, 1 the one before
  * (tasks/monopod.py:95-98,232-235).                                              */
-int os2r_get_action_history(Os2rSim* sim, int which, void* out_dev, void* stream);
-int os2r_set_action_history(Os2rSim* sim, int which, const void* in_dev, void* stream);
+OS2R_API int os2r_get_action_history(Os2rSim* sim, int which, void* out_dev, void* stream);
+OS2R_API int os2r_set_action_history(Os2rSim* sim, int which, const void* in_dev, void* stream);
 
 /* Per-env parameter arrays (domain randomisation), SoA [count][num_envs]. */
-int os2r_set_params(Os2rSim* sim, int field, const void* src_dev, void* stream);
-int os2r_get_params(Os2rSim* sim, int field, void* dst_dev, void* stream);
+OS2R_API int os2r_set_params(Os2rSim* sim, int field, const void* src_dev, void* stream);
+OS2R_API int os2r_get_params(Os2rSim* sim, int field, void* dst_dev, void* stream);
 
 /* Episode bookkeeping: elapsed steps (int32), episode index (uint32), reset pose
  * id (uint8, info['reset_orientation']); any pointer may be NULL.               */
-int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_dev,
+OS2R_API int os2r_get_episode_info(Os2rSim* sim, int32_t* steps_dev, uint32_t* episode_dev,
                           uint8_t* pose_dev, void* stream);
 /* The inverse (any pointer may be NULL): together with os2r_set_state, os2r_set_action_history, os2r_set_params
  * and os2r_set_step_count it restores a handle exactly -- a checkpoint resumed on another handle continues bit
  * for bit (the reference has no save/restore, only env.seed).                                              */
-int os2r_set_episode_info(Os2rSim* sim, const int32_t* steps_dev, const uint32_t* episode_dev,
+OS2R_API int os2r_set_episode_info(Os2rSim* sim, const int32_t* steps_dev, const uint32_t* episode_dev,
                           const uint8_t* pose_dev, void* stream);
 
 /* Global step counter that keys the on-device action RNG. */
-int os2r_get_step_count(Os2rSim* sim, uint64_t* out);
-int os2r_set_step_count(Os2rSim* sim, uint64_t value);
+OS2R_API int os2r_get_step_count(Os2rSim* sim, uint64_t* out);
+OS2R_API int os2r_set_step_count(Os2rSim* sim, uint64_t value);
 
 /* Timing helper for benchmarks: runs `nsteps` os2r_step launches with on-device
  * random actions on the given stream, bracketed by HIP events recorded on that
@@ -279,10 +312,10 @@ int os2r_set_step_count(Os2rSim* sim, uint64_t value);
  * buffers: the timed launch is the one a gym-level env.step makes.
  * elapsed_ms == NULL: the launches are only enqueued (no events, no synchronisation) -- for a caller that drives
  * several handles on several streams (shards of one batch that advance independently) and times them itself.  */
-int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
+OS2R_API int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms);
 /* The same for `count` handles on `count` streams -- the shards of one batch --, enqueue only: step k of every shard is
  * enqueued before step k + 1 of any (round robin), so that all the streams start together.                        */
-int os2r_bench_steps_multi(Os2rSim* const* sims, void* const* streams, int count, int nsteps);
+OS2R_API int os2r_bench_steps_multi(Os2rSim* const* sims, void* const* streams, int count, int nsteps);
 
 /* Work counters (measurement support, bench.py's roofline): while a buffer of OS2R_NUM_WORK_COUNTERS uint64 (device
  * memory, zeroed by the caller) is set, os2r_step launches the counting variant of the step kernel -- the same
@@ -294,16 +327,16 @@ int os2r_bench_steps_multi(Os2rSim* const* sims, void* const* streams, int count
  * with ground contact, the default sweep counts and a reference task layout (OS2R_ERR_INVALID otherwise).
  * NULL switches counting off.                                                                                   */
 #define OS2R_NUM_WORK_COUNTERS 10
-int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
+OS2R_API int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
 
 /* Done reasons (replaces the debug line that names the observation which caused a reset,
  * gym_os2r/tasks/monopod.py:288-296): while a buffer of num_envs uint16 (device memory) is set, every os2r_step
  * writes per environment which observation slots were outside the reset space at the end of the step -- bit d:
  * slot d of the task's observation layout (a non-finite value counts) -- i.e. what set bit0 of `done`; 0 for an
  * environment that is not done or only truncated.  NULL switches it off.                                       */
-int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev);
+OS2R_API int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev);
 
-const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */
+OS2R_API const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */
 
 #ifdef __cplusplus
 }

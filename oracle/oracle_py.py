@@ -223,6 +223,19 @@ class OracleSim:
         assert q.shape == (self.nq, self.N) and qd.shape == (self.nq, self.N)
         lib().orc_set_state(self._h, _p(q), _p(qd))
 
+    def get_solver_state(self):
+        """(lam [4*nq, N], flags uint32 [N]): the impulses that ended every environment's last physics iteration, in the
+        layout of os2r_get_solver_state (include/os2r.h)."""
+        lam, flags = np.zeros((4 * self.nq, self.N)), np.zeros(self.N, dtype=np.uint32)
+        lib().orc_get_solver_state(self._h, _p(lam), _p(flags))
+        return lam, flags
+
+    def set_solver_state(self, lam, flags):
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        flags = np.ascontiguousarray(flags, dtype=np.uint32)
+        assert lam.shape == (4 * self.nq, self.N) and flags.shape == (self.N,)
+        lib().orc_set_solver_state(self._h, _p(lam), _p(flags))
+
     def get_action_history(self, which):
         out = np.zeros((2, self.N))
         lib().orc_get_action_history(self._h, int(which), _p(out))

@@ -648,8 +648,8 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
  * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
  * row and measures what it moved.  At most `exact` solves per physics iteration; the sweep cap `iters` still holds. */
-#define ORC_EXACT_FIRST_STD(n) ((n) >= 5 ? 6 : 4)
-#define ORC_EXACT_FIRST(n) (warm_now ? (g_first_override > 0 ? g_first_override : ORC_WARM_FIRST) : ORC_EXACT_FIRST_STD(n))   /* sweeps before the first check: per number of dof */
+#define ORC_EXACT_FIRST_COLD(n) ((n) >= 5 ? 6 : 4)   /* (studies only: sweeps before the first check of a cold start, as in round 3) */
+#define ORC_EXACT_FIRST(n) (cold_now ? ORC_EXACT_FIRST_COLD(n) : g_first)   /* sweeps before the first check */
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX 3
 #define ORC_EXACT_SNAP 1e-12
@@ -772,17 +772,28 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
 /* diagnostics: phase-2 sweeps and exact solves of the calling thread's last solve (orc_get_solver_counts) */
 static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 
-/* Warm start between the physics iterations of one env-step.  From the second iteration on, phase 2 starts from the
- * impulses that ended the previous iteration (clamped into this iteration's box; rows of a body that had no contact then
- * keep what phase 1 gave them): the solution moves by a thousandth per iteration, so ORC_WARM_FIRST sweeps identify the
- * active sets that ORC_EXACT_FIRST_STD cold sweeps do.  The first iteration of an env-step is cold, and so is a single
- * iteration (orc_substep, orc_contact_problem).  Per thread: an environment's iterations run back to back on one thread.
- * (orc_set_experimental_warm: studies -- off, or another number of sweeps after a warm start) */
+/* Warm start of phase 2: the solver state of an environment.  Phase 2 of every physics iteration starts from the impulses
+ * that ended the environment's previous iteration -- of this env-step or of the one before: the state is part of the
+ * environment (OrcSim.warm, orc_get/set_solver_state; the reference's backend keeps one persistent constraint solver per
+ * world behind gym_os2r/runtimes/gazebo_runtime.py:76,111-114) -- clamped into this iteration's box; a row without a
+ * remembered impulse (a body that had no contact then; every row after a reset) keeps what phase 1 gave it.  The solution
+ * moves by a thousandth per iteration, so ORC_WARM_FIRST sweeps identify the active set before the first check.  A single
+ * iteration (orc_substep, orc_contact_problem) starts like the first one after a reset: nothing remembered.
+ * Per thread: an environment's iterations run back to back on one thread; NAN marks "nothing remembered".
+ * (orc_set_experimental_warm, studies: mode 0 -- no warm start, every iteration cold with ORC_EXACT_FIRST_COLD sweeps;
+ *  mode 2 -- round 3: the first iteration of every env-step cold, the state forgotten between env-steps;
+ *  `first` > 0 -- another number of sweeps before the first check of a warm iteration; < 0 -- see the function) */
 #define ORC_WARM_FIRST 3
-static int g_warm = 1, g_first_override = 0;
-void orc_set_experimental_warm(int on, int first) { g_warm = on; g_first_override = first; }
-static _Thread_local double tl_warm[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
-static _Thread_local int tl_warm_valid = 0;
+#define ORC_WARM_ROWS (3 * OS2R_MAX_DOF + OS2R_MAX_DOF)
+#define ORC_WARM_SLOTS (ORC_WARM_ROWS + 1)   /* the last slot: 1.0 once an iteration has left its impulses (the joint rows are remembered) */
+static int g_warm = 1, g_first = ORC_WARM_FIRST, g_solve_always = 0;
+/* first > 0: that many sweeps before the first check; first = -k: k - 1 sweeps, then EVERY environment solves once before its first check */
+void orc_set_experimental_warm(int mode, int first) {
+  g_warm = mode; g_first = first > 0 ? first : (first < 0 ? -first - 1 : ORC_WARM_FIRST); g_solve_always = first < 0;
+}
+static _Thread_local double tl_warm[ORC_WARM_SLOTS];
+static _Thread_local int tl_cold = 0;   /* modes 0 and 2 only */
+static void warm_forget(double* w) { for (int k = 0; k < ORC_WARM_SLOTS; ++k) w[k] = NAN; }
 static int warm_slot(const Row* rows, int r) {
   const Row* R = &rows[r];
   if (R->kind == 0) return 3 * R->body;
@@ -801,14 +812,14 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         r += 2;
       }
   if (normal_iters <= 0) exact = 0;               /* the coupled pyramid has no fixed box to pivot on */
-  const int warm_now = g_warm && tl_warm_valid && exact > 0;
+  const int cold_now = g_warm == 0 || tl_cold;
   double lc[OS2R_MAX_DOF * OS2R_MAX_DOF];
   if (exact > 0) chol_lower(n, minv, lc);
   for (int phase = 0; phase < 2; ++phase) {
     const int sweeps = phase == 0 ? normal_iters : iters;
     if (phase == 1 && normal_iters > 0)
       for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
-    if (phase == 1 && exact > 0 && g_warm && tl_warm_valid && nr <= 3 * OS2R_MAX_DOF + OS2R_MAX_DOF)
+    if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS)
       for (int r = 0; r < nr; ++r) {
         Row* R = &rows[r];
         const double w0 = tl_warm[warm_slot(rows, r)];
@@ -849,13 +860,14 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
       if (phase == 1 && it + 1 < sweeps && moved <= tol) {
-        if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) : (it + 1) % ORC_PGS_GROUP == 0) break;
+        if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) && !(g_solve_always && solves == 0) : (it + 1) % ORC_PGS_GROUP == 0) break;
       }
     }
-    if (phase == 1 && g_warm && nr <= 3 * OS2R_MAX_DOF + OS2R_MAX_DOF) {
-      for (int k = 0; k < 3 * OS2R_MAX_DOF + OS2R_MAX_DOF; ++k) tl_warm[k] = NAN;
+    if (phase == 1 && exact > 0 && g_warm && nr <= ORC_WARM_ROWS) {
+      warm_forget(tl_warm);
       for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0) tl_warm[warm_slot(rows, r)] = rows[r].lambda;
-      tl_warm_valid = 1;
+      tl_warm[ORC_WARM_ROWS] = 1.0;
+      tl_cold = 0;
     }
   }
 }
@@ -877,7 +889,7 @@ static void substep_model(const Os2rConfig* cfg, int contact_model, const EnvPar
 }
 
 static void substep(const Os2rConfig* cfg, const EnvParams* ep, double* q, double* qd, const double tau2[2]) {
-  tl_warm_valid = 0;   /* a single iteration: nothing remembered */
+  warm_forget(tl_warm); tl_cold = g_warm != 1;   /* a single iteration: nothing remembered */
   substep_model(cfg, ORC_CONTACT_CENTROID, ep, q, qd, tau2);
 }
 
@@ -902,7 +914,7 @@ void orc_substep_model(const Os2rConfig* cfg, int contact_model, const double* m
                        const double* friction, const double* mu, double gravity_z, double* q, double* qd,
                        const double tau2[2]) {
   EnvParams ep; params_from(cfg, mass_scale, damping, friction, mu, gravity_z, &ep);
-  tl_warm_valid = 0;
+  warm_forget(tl_warm); tl_cold = g_warm != 1;
   substep_model(cfg, contact_model, &ep, q, qd, tau2);
 }
 
@@ -931,7 +943,7 @@ int orc_contact_problem(const Os2rConfig* cfg, int contact_model, const double* 
     for (int i = 0; i < 3; ++i) point[3 * r + i] = rows[r].point[i];
   }
   const int coupled = contact_model != ORC_CONTACT_CENTROID || cfg->pgs_normal_iters == 0;
-  tl_warm_valid = 0;
+  warm_forget(tl_warm); tl_cold = g_warm != 1;
   solve_rows(n, rows, nr, coupled ? 0 : cfg->pgs_normal_iters, cfg->pgs_iters, cfg->pgs_tol, coupled ? 0 : cfg->pgs_exact, minv, v);
   for (int r = 0; r < nr; ++r) {
     lambda[r] = rows[r].lambda;
@@ -958,6 +970,7 @@ struct OrcSim {
   uint64_t step_count;
   int nthreads;
   int contact_model;   /* ORC_CONTACT_*: the specification unless a test asks for the comparison model */
+  double* warm;            /* [N][ORC_WARM_SLOTS]: the solver state (impulses that ended the last physics iteration; NAN: none) */
   int8_t* solver_counts; /* diagnostics, [2][substeps][N]: phase-2 sweeps / exact solves of every physics iteration of the last step */
 };
 
@@ -1011,6 +1024,7 @@ static void reset_env(OrcSim* s, int64_t e) {
   for (int i = 0; i < n; ++i) { s->q[i * N + e] = qn[i]; s->qd[i * N + e] = 0.0; }
   s->pose[e] = (uint8_t)ts->reset_pose_id[pi];
   s->steps[e] = 0;
+  warm_forget(s->warm + (size_t)e * ORC_WARM_SLOTS);   /* a new episode: the solver remembers nothing */
   if (ts->reset_mode == OS2R_RESET_RANDOM && ts->randomize_params) {
     const Os2rModel* md = &cfg->model;
     for (int i = 0; i < n; ++i) {
@@ -1041,6 +1055,7 @@ int orc_create(const Os2rConfig* cfg, OrcSim** out) {
   s->mass_scale = calloc(n * N, 8); s->damping = calloc(n * N, 8); s->friction = calloc(n * N, 8);
   s->mu = calloc(n * N, 8); s->gravity = calloc(N, 8);
   s->steps = calloc(N, 4); s->episode = calloc(N, 4); s->pose = calloc(N, 1);
+  s->warm = malloc((size_t)N * ORC_WARM_SLOTS * 8);
   for (int64_t e = 0; e < N; ++e) {
     for (int i = 0; i < n; ++i) {
       s->mass_scale[i * N + e] = 1.0; s->damping[i * N + e] = cfg->model.damping[i];
@@ -1060,7 +1075,7 @@ int orc_create(const Os2rConfig* cfg, OrcSim** out) {
 void orc_destroy(OrcSim* s) {
   if (!s) return;
   free(s->q); free(s->qd); free(s->hist); free(s->mass_scale); free(s->damping); free(s->friction);
-  free(s->mu); free(s->gravity); free(s->steps); free(s->episode); free(s->pose); free(s->solver_counts); free(s);
+  free(s->mu); free(s->gravity); free(s->steps); free(s->episode); free(s->pose); free(s->warm); free(s->solver_counts); free(s);
 }
 
 void orc_set_threads(OrcSim* s, int n) { s->nthreads = n < 1 ? 1 : n; }
@@ -1110,7 +1125,8 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
     double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
     EnvParams ep; load_params(s, e, &ep);
     for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
-    tl_warm_valid = 0;
+    if (g_warm == 1) { memcpy(tl_warm, s->warm + (size_t)e * ORC_WARM_SLOTS, sizeof tl_warm); tl_cold = 0; }
+    else { warm_forget(tl_warm); tl_cold = 1; }
     for (int k = 0; k < cfg->substeps; ++k) {                                                          /* gazebo_runtime.py:70-77 */
       substep_model(cfg, s->contact_model, &ep, q, qd, tau);
       if (s->solver_counts) {
@@ -1118,6 +1134,7 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
         s->solver_counts[((size_t)cfg->substeps + k) * s->N + e] = (int8_t)(tl_last_solves > 127 ? 127 : tl_last_solves);
       }
     }
+    if (g_warm == 1) memcpy(s->warm + (size_t)e * ORC_WARM_SLOTS, tl_warm, sizeof tl_warm);
     int bad = 0;
     for (int i = 0; i < n; ++i) { if (!isfinite(q[i]) || !isfinite(qd[i])) bad = 1; s->q[i * N + e] = q[i]; s->qd[i * N + e] = qd[i]; }
     /* action_history.appendleft (monopod.py:232-235) */
@@ -1153,6 +1170,39 @@ int orc_set_state(OrcSim* s, const double* q, const double* qd) {
   size_t b = (size_t)s->cfg.model.nq * s->N * 8;
   if (q) memcpy(s->q, q, b);
   if (qd) memcpy(s->qd, qd, b);
+  for (int64_t e = 0; e < s->N; ++e) warm_forget(s->warm + (size_t)e * ORC_WARM_SLOTS);   /* as os2r_set_state: starts like a reset */
+  return OS2R_OK;
+}
+/* The solver state in the layout of include/os2r.h (os2r_get_solver_state): lam [4*nq][N] -- rows b, nq + b, 2nq + b: normal
+ * and the two tangential impulses of body b's contact, row 3nq + j: friction impulse of joint j --, flags [N]: bit b: body b
+ * had a contact in the environment's last physics iteration, bit 31: an iteration has run since the reset. */
+int orc_get_solver_state(OrcSim* s, double* lam, uint32_t* flags) {
+  const int n = s->cfg.model.nq; const int64_t N = s->N;
+  for (int64_t e = 0; e < N; ++e) {
+    const double* w = s->warm + (size_t)e * ORC_WARM_SLOTS;
+    uint32_t f = isnan(w[ORC_WARM_ROWS]) ? 0u : 0x80000000u;
+    for (int b = 0; b < n; ++b) {
+      if (!isnan(w[3 * b])) f |= 1u << b;
+      if (lam) for (int t = 0; t < 3; ++t) lam[(size_t)(t * n + b) * N + e] = isnan(w[3 * b + t]) ? 0.0 : w[3 * b + t];
+      if (lam) lam[(size_t)(3 * n + b) * N + e] = isnan(w[3 * OS2R_MAX_DOF + b]) ? 0.0 : w[3 * OS2R_MAX_DOF + b];
+    }
+    if (flags) flags[e] = f;
+  }
+  return OS2R_OK;
+}
+int orc_set_solver_state(OrcSim* s, const double* lam, const uint32_t* flags) {
+  const int n = s->cfg.model.nq; const int64_t N = s->N;
+  if (!lam || !flags) return OS2R_ERR_INVALID;
+  for (int64_t e = 0; e < N; ++e) {
+    double* w = s->warm + (size_t)e * ORC_WARM_SLOTS;
+    warm_forget(w);
+    const uint32_t f = flags[e];
+    if (f & 0x80000000u) w[ORC_WARM_ROWS] = 1.0;
+    for (int b = 0; b < n; ++b) {
+      if ((f >> b) & 1u) for (int t = 0; t < 3; ++t) w[3 * b + t] = lam[(size_t)(t * n + b) * N + e];
+      if (f & 0x80000000u) w[3 * OS2R_MAX_DOF + b] = lam[(size_t)(3 * n + b) * N + e];
+    }
+  }
   return OS2R_OK;
 }
 int orc_get_action_history(OrcSim* s, int which, double* out) { memcpy(out, s->hist + (size_t)which * 2 * s->N, 2 * s->N * 8); return OS2R_OK; }

@@ -51,7 +51,9 @@ void orc_set_contact_model(OrcSim* s, int model);
 int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves);   /* diagnostics: [substeps][N] each, of the last step; the first call switches recording on */
 void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
 void orc_set_experimental_row_order(int order);
-void orc_set_experimental_warm(int on, int first);   /* tests and studies: warm start between iterations off, or K sweeps after it */
+void orc_set_experimental_warm(int mode, int first);  /* studies: 1 the specification, 0 no warm start, 2 round 3 (forgotten between env-steps); K sweeps before the first check */
+int orc_get_solver_state(OrcSim* s, double* lam, uint32_t* flags);   /* layout of os2r_get_solver_state (include/os2r.h) */
+int orc_set_solver_state(OrcSim* s, const double* lam, const uint32_t* flags);
 int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);
 int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint8_t* done, double* term_obs);
 int orc_get_state(OrcSim* s, double* q, double* qd);

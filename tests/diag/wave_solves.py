@@ -59,6 +59,10 @@ def main():
         hist += np.bincount(so.ravel(), minlength=16)[:16]
         last = (sw, so)
     T, R = np.concatenate(tots), np.concatenate(rounds) - first * cfg.substeps
+    # modelled phase-2 time of a wave and env-step: 1050 ticks a sweep, 4200 a solve (profiles/r03_stamps_C4.txt)
+    M = 1050.0 * np.concatenate(rounds) + 4200.0 * T
+    print(f"  modelled phase-2 ticks per wave and env-step: mean {M.mean() / 1e3:.1f} k  p99 {np.percentile(M, 99) / 1e3:.1f} k  max {M.max() / 1e3:.1f} k"
+          f"  (first sweeps {first})")
     print(f"{a.workload}, {cfg.num_envs} envs = {W} waves, {a.steps} env-steps after {a.preroll}, warm start {'on' if a.warm else 'off'}")
     print(f"  exact solves per wave and env-step: mean {T.mean():.2f}  p50 {np.percentile(T, 50):.0f}  p90 {np.percentile(T, 90):.0f}  "
           f"p99 {np.percentile(T, 99):.0f}  max {T.max()};  re-test sweeps: mean {R.mean():.2f}  p99 {np.percentile(R, 99):.0f}  max {R.max()}")

@@ -45,8 +45,13 @@ def _worker(rank, world, port, total, q):
     for _ in range(8):
         obs, rew, done, _ = sim.step(None)           # counter-RNG actions keyed by the global env index
     dist.barrier()                                   # no collective on the step path; this is the bench bracket
-    g_obs = gather_to_rank0(torch.from_numpy(obs), total)
-    g_done = gather_to_rank0(torch.from_numpy(done), total)
+    g_obs = gather_to_rank0(torch.from_numpy(obs), total, key="obs")
+    g_done = gather_to_rank0(torch.from_numpy(done), total, key="done")
+    # the gather writes into one preallocated output per key: a second call returns the same storage, refilled
+    again = gather_to_rank0(torch.from_numpy(obs) * 0 + float(rank), total, key="obs")
+    if rank == 0:
+        assert again.data_ptr() == g_obs.data_ptr() and float(again[0, 0]) == 0.0 and float(again[-1, 0]) == float(world - 1)
+    g_obs = gather_to_rank0(torch.from_numpy(obs), total, key="obs")
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)         # max-over-ranks timing reduction used by bench.py
     assert float(t) == world
@@ -58,8 +63,10 @@ def _worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_reproduce_the_single_handle_run(oracle):
-    total, world, port = 37, 2, 29533                 # odd total: uneven shards (19 + 18)
+@pytest.mark.parametrize("total,world,port", [(37, 2, 29533), (36, 2, 29535), (9, 1, 29537)])
+def test_two_rank_shards_reproduce_the_single_handle_run(oracle, total, world, port):
+    """uneven shards (19 + 18: padded staging block), even shards (the collective writes straight into the output's slices),
+    and a single rank (the collective still runs: what the one-GPU rehearsal of bench.py executes)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]

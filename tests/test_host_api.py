@@ -196,6 +196,13 @@ def test_capi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), name
+    # ... and nothing else is: the dynamic symbol table of the library is the header (-fvisibility=hidden + csrc/libos2r.map)
+    import shutil
+    import subprocess
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+        assert exported == declared, sorted(exported ^ declared)[:10]
     assert lib.os2r_abi_version() == abi.ABI_VERSION
     lib.os2r_last_error.restype = ctypes.c_char_p
     # struct layout agreement between the header (as compiled) and the ctypes mirror
@@ -444,13 +451,19 @@ def test_code_objects_of_the_built_library_have_no_scratch_and_no_runtime_tables
     assert sum("StModel<" in k for k in steps) >= 48 and sum("RtModel<" in k for k in steps) >= 32   # compiled-in robots; generic kernels
     # One phase-2 solver per kernel (the exact finish or the sweeps-only solver, chosen at launch) keeps even the generic
     # 5-dof fp64 contact kernels, which carry the rows of five bodies, inside the 512 registers: no scratch anywhere.
+    rollouts = 0
     for name, m in steps.items():
-        assert m["private_segment_fixed_size"] == 0, (name, m)      # (spills into AGPRs are counted in vgpr_spill_count; they are not scratch)
+        # the last template argument: the fused K-step variants of os2r_rollout (the step loop around the same body).  One of
+        # them -- fp64, 5 dof, per-env parameters: every register is taken -- keeps 8 registers in 36 B of scratch.
+        rollout = re.search(r", true>\(os2r::StepArgs<", name) is not None and re.search(r", (true|false), \d, true>\(", name) is not None
+        rollouts += rollout
+        assert m["private_segment_fixed_size"] <= (40 if rollout else 0), (name, m)   # (spills into AGPRs are counted in vgpr_spill_count; they are not scratch)
         assert m["vgpr_spill_count"] <= 8, (name, m)                # AGPR spill slots of the register allocator, a handful at most
         if "step_kernel<float" in name:
             assert m["vgpr_count"] <= 256, (name, m["vgpr_count"])
-        if "StModel<" in name and "os2r::StLayout" in name:
+        if "StModel<" in name and "os2r::StLayout" in name and not rollout:
             assert m["vgpr_spill_count"] <= 2, (name, m)             # the kernels of the reference's task modes
+    assert rollouts >= 20, rollouts
     tables = []
     for co in kernel_meta.code_objects(_lib.LIB_PATH):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
