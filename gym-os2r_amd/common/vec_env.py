@@ -44,7 +44,9 @@ class HipVecEnv:
             return None
         if self._streams is None:
             import torch
-            dev = self.envs[0].unwrapped.sim.device
+            # (the device from the runtime's options: touching `.sim` here would create the handle -- and its first reset -- early)
+            dev = self.envs[0].unwrapped._opts.get("device")
+            dev = torch.device(dev if dev is not None else "cuda:0")
             self._streams = [torch.cuda.Stream(device=dev) for _ in self.envs]
         return self._streams[i]
 
@@ -126,7 +128,7 @@ class HipVecEnv:
             return self.env.reset()
         import torch
         # every shard resets on its own stream, behind whatever it was last given, and the caller's stream waits for all
-        cur = torch.cuda.current_stream(self.envs[0].unwrapped.sim.device)
+        cur = torch.cuda.current_stream(self._stream_of(0).device)
         out = []
         for i, e in enumerate(self.envs):
             st = self._stream_of(i)

@@ -966,7 +966,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // the kernels built for the default solver settings, in per-lane LDS slots in the others (their register file is full
   // during the exact solves, see kMuInLds below)
   constexpr bool kStdExact = sizeof(T) == 8 && SOLVER == kSolverExact && MD::kStatic;   // the kernels that have registers to spare
-  constexpr bool kParkY0 = sizeof(T) == 8 && SOLVER != kSolverSweeps && !kStdExact;
+  // (the generic fp64 kernels park it whatever their solver: with rows for every body their register file is full)
+  constexpr bool kParkY0 = sizeof(T) == 8 && !kStdExact && (SOLVER != kSolverSweeps || !MD::kStatic);
   constexpr int kY0Slot = NQ * (NQ + 1) / 2 + 3 * NQ + NQ;   // behind the factor's mirror and the multipliers' slots
   static_assert(kY0Slot + NQ <= 8 * NQ, "per-lane LDS slots");
   T y0[NQ];

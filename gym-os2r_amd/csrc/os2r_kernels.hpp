@@ -523,19 +523,29 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
       );
     }
     __syncthreads();
+    // Everything behind the physics iterations addresses the environment through a value the compiler cannot see through:
+    // otherwise the addresses of the arrays stored below -- sixty 64-bit values -- are computed at the top of the kernel and
+    // held in registers across the physics loop (measured: 36 AGPR copies more for the solver's state alone).
+    long long ep = e;
+    asm volatile("" : "+v"(ep));
+    // ... and reads the kernel arguments afresh from the argument segment: held in scalar registers from the top of the kernel
+    // they (two dozen pointers) are spilled to VGPR lanes across the physics loop
+    const OS2R_CONST StepArgs<T>* args_e = (const OS2R_CONST StepArgs<T>*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(args_e));
+    const StepArgs<T>& Ae = *(const StepArgs<T>*)args_e;
     // The contact solver's state goes back to HBM here, straight after the last physics iteration: held until the end of
     // the env-step it would be live across the whole epilogue -- forty registers more at the kernel's widest point.
     if constexpr (kCarry) {
       if (valid) {
-        A.solver_flags[e] = carry.act;
+        Ae.solver_flags[ep] = carry.act;
 #pragma unroll
         for (int b = 0; b < NQ; ++b) {
           // (an impulse that is not remembered is stored as zero: the arrays are a function of the trajectory alone)
           const bool cb = ((carry.act >> b) & 1u) != 0u;
-          A.solver_l[(0 * NQ + b) * A.N + e] = cb ? carry.ln[b] : T(0);
-          A.solver_l[(1 * NQ + b) * A.N + e] = cb ? carry.lx[b] : T(0);
-          A.solver_l[(2 * NQ + b) * A.N + e] = cb ? carry.ly[b] : T(0);
-          A.solver_l[(3 * NQ + b) * A.N + e] = carry.lf[b];
+          Ae.solver_l[(0 * NQ + b) * Ae.N + ep] = cb ? carry.ln[b] : T(0);
+          Ae.solver_l[(1 * NQ + b) * Ae.N + ep] = cb ? carry.lx[b] : T(0);
+          Ae.solver_l[(2 * NQ + b) * Ae.N + ep] = cb ? carry.ly[b] : T(0);
+          Ae.solver_l[(3 * NQ + b) * Ae.N + ep] = carry.lf[b];
         }
       }
     }
@@ -546,7 +556,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
 
     // (the bookkeeping of an environment -- action history, step and episode counters -- is fetched where it is used and
     // stored at the end of every env-step, in a rollout as well: nothing of it is held across the physics iterations)
-    const T h1x = A.hist[0 * A.N + e], h1y = A.hist[1 * A.N + e];  // becomes action_history[1]
+    const T h1x = Ae.hist[0 * Ae.N + ep], h1y = Ae.hist[1 * Ae.N + ep];  // becomes action_history[1]
     T obs[OS2R_MAX_OBS];
     bool dn;
     unsigned why;
@@ -555,19 +565,19 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     OS2R_STAMP(21);
     const T rew = reward_of<T>(ts, obs, asx, asy, h1x, h1y);
     OS2R_STAMP(22);
-    int steps = A.steps[e] + 1;
+    int steps = Ae.steps[ep] + 1;
     const bool trunc = ts->max_episode_steps > 0 && steps >= ts->max_episode_steps;
     const uint8_t flag = (uint8_t)((dn ? 1 : 0) | (trunc ? 2 : 0) | (bad ? 4 : 0));
 
-    if (A.term_obs) store_obs_tile<T>(A.term_obs + ko * D, obs, D, e0, A.N, lane, tile);
+    if (Ae.term_obs) store_obs_tile<T>(Ae.term_obs + ko * D, obs, D, e0, Ae.N, lane, tile);
 
-    uint32_t epi = A.episode[e];
-    uint8_t pose = A.pose[e];
-    const bool do_reset = flag != 0 && A.auto_reset != 0;
+    uint32_t epi = Ae.episode[ep];
+    uint8_t pose = Ae.pose[ep];
+    const bool do_reset = flag != 0 && Ae.auto_reset != 0;
     ParamVals<T, NQ> pv;
     if (__ballot(do_reset) != 0ull) {
       if (do_reset) {
-        reset_env<T, MD, DR>(A, e, epi, q, qd, pv, pose);
+        reset_env<T, MD, DR>(Ae, ep, epi, q, qd, pv, pose);
         epi += 1;
         steps = 0;
         bool dn2;
@@ -576,35 +586,35 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
         // a new episode: the contact solver remembers nothing
         if constexpr (kCarry) {
           if (valid) {
-            A.solver_flags[e] = 0u;
+            Ae.solver_flags[ep] = 0u;
 #pragma unroll
-            for (int k = 0; k < 4 * NQ; ++k) A.solver_l[k * A.N + e] = T(0);
+            for (int k = 0; k < 4 * NQ; ++k) Ae.solver_l[k * Ae.N + ep] = T(0);
           }
         }
       }
     }
-    if (A.obs) store_obs_tile<T>(A.obs + ko * D, obs, D, e0, A.N, lane, tile);
+    if (Ae.obs) store_obs_tile<T>(Ae.obs + ko * D, obs, D, e0, Ae.N, lane, tile);
     OS2R_STAMP(23);
     if (valid) {
-      A.hist[2 * A.N + e] = h1x;
-      A.hist[3 * A.N + e] = h1y;
-      A.hist[0 * A.N + e] = asx;
-      A.hist[1 * A.N + e] = asy;
-      A.steps[e] = steps;
+      Ae.hist[2 * Ae.N + ep] = h1x;
+      Ae.hist[3 * Ae.N + ep] = h1y;
+      Ae.hist[0 * Ae.N + ep] = asx;
+      Ae.hist[1 * Ae.N + ep] = asy;
+      Ae.steps[ep] = steps;
       if (do_reset) {
-        A.episode[e] = epi;
-        A.pose[e] = pose;
-        store_params<T, NQ>(A, e, pv);
+        Ae.episode[ep] = epi;
+        Ae.pose[ep] = pose;
+        store_params<T, NQ>(Ae, ep, pv);
       }
-      if (A.reward) A.reward[ko + e] = rew;
-      if (A.done) A.done[ko + e] = flag;
-      if (A.reason) A.reason[ko + e] = (uint16_t)why;
+      if (Ae.reward) Ae.reward[ko + ep] = rew;
+      if (Ae.done) Ae.done[ko + ep] = flag;
+      if (Ae.reason) Ae.reason[ko + ep] = (uint16_t)why;
     }
     if (valid) {
 #pragma unroll
       for (int i = 0; i < NQ; ++i) {
-        A.q[i * A.N + e] = q[i];
-        A.qd[i * A.N + e] = qd[i];
+        Ae.q[i * Ae.N + ep] = q[i];
+        Ae.qd[i * Ae.N + ep] = qd[i];
       }
     }
     if constexpr (ROLLOUT) {

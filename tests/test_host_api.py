@@ -453,11 +453,17 @@ def test_code_objects_of_the_built_library_have_no_scratch_and_no_runtime_tables
     # 5-dof fp64 contact kernels, which carry the rows of five bodies, inside the 512 registers: no scratch anywhere.
     rollouts = 0
     for name, m in steps.items():
-        # the last template argument: the fused K-step variants of os2r_rollout (the step loop around the same body).  One of
-        # them -- fp64, 5 dof, per-env parameters: every register is taken -- keeps 8 registers in 36 B of scratch.
+        # the last template argument: the fused K-step variants of os2r_rollout (the step loop around the same body)
         rollout = re.search(r", true>\(os2r::StepArgs<", name) is not None and re.search(r", (true|false), \d, true>\(", name) is not None
         rollouts += rollout
-        assert m["private_segment_fixed_size"] <= (40 if rollout else 0), (name, m)   # (spills into AGPRs are counted in vgpr_spill_count; they are not scratch)
+        if m["private_segment_fixed_size"] != 0:
+            # a few bytes reserved for the register allocator's SGPR spill bookkeeping are no scratch traffic: the kernel may
+            # then hold no vector spill and no scratch instruction (read from its disassembly)
+            import isa_histogram
+            needle = name[name.index("step_kernel<"):name.index(">(os2r::StepArgs") + 2]
+            _, _, insts = isa_histogram.disassemble(_lib.LIB_PATH, needle, counting=", true, " in needle[-20:])
+            assert m["vgpr_spill_count"] == 0 and not [i for i in insts if i[1].startswith("scratch_")], (name, m)
+            assert m["private_segment_fixed_size"] <= 68, (name, m)
         assert m["vgpr_spill_count"] <= 8, (name, m)                # AGPR spill slots of the register allocator, a handful at most
         if "step_kernel<float" in name:
             assert m["vgpr_count"] <= 256, (name, m["vgpr_count"])

@@ -66,8 +66,11 @@ def disassemble(path, needle, counting=False):
             funcs = [ln.split() for ln in syms.splitlines() if " FUNC " in ln]
             names = [x[7] for x in funcs]
             for x, dn in zip(funcs, demangle(names)):
-                is_counting = re.search(r", true(, \d+)?>\(os2r::StepArgs<", dn) is not None   # the COUNT template argument
-                if needle in dn and is_counting == counting:
+                # the last template arguments: COUNT, SOLVER, ROLLOUT (the fused K-step variants are listed only when asked for by name)
+                tail = re.search(r", (true|false), (\d+), (true|false)>\(os2r::StepArgs<", dn)
+                is_counting = tail is not None and tail.group(1) == "true"
+                is_rollout = tail is not None and tail.group(3) == "true"
+                if needle in dn and is_counting == counting and (not is_rollout or "true>(" in needle):
                     dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", f"--disassemble-symbols={x[7]}", f.name],
                                          capture_output=True, text=True).stdout
                     insts = []
