@@ -188,6 +188,13 @@ class OracleSim:
             return None
         return sw, so
 
+    def small_solve_counts(self):
+        """int8 [substeps, N]: how many of the exact solves of solver_counts() were dual solves of a small free set."""
+        sm = np.zeros((int(self.cfg.substeps), self.N), dtype=np.int8)
+        if lib().orc_get_small_solve_counts(self._h, _p(sm)):
+            return None
+        return sm
+
     def close(self):
         if self._h:
             lib().orc_destroy(self._h)

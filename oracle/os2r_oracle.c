@@ -661,6 +661,19 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * ORC_EXACT_INCONS of what it found (squared norms), it goes on in the direction of its multipliers -- past the full
  * step -- to the first bound it meets, sets that row on it and solves again, as after a cut. */
 #define ORC_EXACT_INCONS 1e-4
+/* Small free sets (round 4).  In the regimes the stepper lives in, an environment that needs a solve has two free rows
+ * -- the normal and one tangential row of a sticking-sliding contact, or the normals of two contacts -- seldom three and
+ * hardly ever more (joints slide: their friction rows sit on their bounds).  A free set of at most ORC_EXACT_SMALL rows
+ * is therefore solved in the DUAL: A mu = -w with A = G_F G_F^T (m x m, L D L^T in sweep order, no pivoting), the impulses
+ * move by mu and the velocity by Minv J_F^T mu -- the same equality-constrained minimum as the regularised 5 x 5 solve
+ * below, reached with a tenth of the arithmetic -- with the same cut at the first bound.  A set whose rows are (nearly)
+ * dependent -- a pivot below ORC_EXACT_SMALL_PIVOT of its diagonal entry -- or larger takes the regularised solve, which
+ * is made for that. */
+#define ORC_EXACT_SMALL 3
+#define ORC_EXACT_SMALL_PIVOT 1e-8
+static int g_small = 1;   /* (orc_set_experimental_small: studies -- 0 switches the dual solve of small free sets off) */
+void orc_set_experimental_small(int on) { g_small = on; }
+static _Thread_local int tl_last_small = 0;   /* diagnostics: dual solves among the solves of the last iteration */
 
 static void chol_lower(int n, const double* a, double* l) {   /* a = l l^T, row-major n x n */
   for (int i = 0; i < n * n; ++i) l[i] = 0.0;
@@ -700,6 +713,65 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
   }
   for (int i = 0; i < n; ++i) tr += S[i][i];
   if (!(tr > 0.0)) return 0;                       /* no free row: nothing to solve */
+  /* ---- a small, well-conditioned free set: the dual solve ---- */
+  {
+    int F[ORC_EXACT_SMALL], m = 0, small = g_small;
+    for (int r = 0; r < nr && small; ++r) if (fr[r]) { if (m < ORC_EXACT_SMALL) F[m++] = r; else small = 0; }
+    if (small && m > 0) {
+      double A[ORC_EXACT_SMALL][ORC_EXACT_SMALL], L[ORC_EXACT_SMALL][ORC_EXACT_SMALL] = {{0}}, D[ORC_EXACT_SMALL], mu_[ORC_EXACT_SMALL];
+      for (int a = 0; a < m; ++a) for (int b = 0; b <= a; ++b) {
+        double t = 0; for (int k = 0; k < n; ++k) t += g[F[a]][k] * g[F[b]][k];
+        A[a][b] = t;
+      }
+      for (int a = 0; a < m && small; ++a) {       /* L D L^T, rows in sweep order */
+        double d = A[a][a];
+        for (int b = 0; b < a; ++b) {
+          double t = A[a][b];
+          for (int c = 0; c < b; ++c) t -= L[a][c] * L[b][c] * D[c];
+          L[a][b] = t / D[b];
+          d -= L[a][b] * L[a][b] * D[b];
+        }
+        D[a] = d;
+        if (!(d > ORC_EXACT_SMALL_PIVOT * A[a][a])) small = 0;   /* dependent rows: the regularised solve below */
+      }
+      if (small) {
+        for (int a = 0; a < m; ++a) { double t = -w[F[a]]; for (int b = 0; b < a; ++b) t -= L[a][b] * mu_[b]; mu_[a] = t; }
+        for (int a = 0; a < m; ++a) mu_[a] /= D[a];
+        for (int a = m - 1; a >= 0; --a) for (int b = a + 1; b < m; ++b) mu_[a] -= L[b][a] * mu_[b];
+        int cut = 0;
+        for (int a = 0; a < m; ++a) {
+          double lo, hi; row_box(rows, &rows[F[a]], 1, &lo, &hi);
+          const double full = rows[F[a]].lambda + mu_[a];
+          if (full < lo || full > hi) cut = 1;
+        }
+        double alpha = 1.0;
+        if (cut)
+          for (int a = 0; a < m; ++a) {
+            if (mu_[a] == 0.0) continue;
+            double lo, hi; row_box(rows, &rows[F[a]], 1, &lo, &hi);
+            if (mu_[a] > 0.0 && !isfinite(hi)) continue;
+            const double lim = ((mu_[a] > 0.0 ? hi : lo) - rows[F[a]].lambda) / mu_[a];
+            if (lim < alpha) alpha = lim;
+          }
+        for (int a = 0; a < m; ++a) {
+          Row* R = &rows[F[a]];
+          double lo, hi; row_box(rows, R, 1, &lo, &hi);
+          const double l = R->lambda;
+          double nl = l + alpha * mu_[a];
+          if (cut) {
+            if (mu_[a] > 0.0 && isfinite(hi) && hi - nl <= ORC_EXACT_SNAP * (hi - l)) nl = hi;
+            if (mu_[a] < 0.0 && nl - lo <= ORC_EXACT_SNAP * (l - lo)) nl = lo;
+          }
+          if (nl < lo) nl = lo;
+          if (nl > hi) nl = hi;
+          R->lambda = nl;
+          for (int j = 0; j < n; ++j) v[j] += R->T[j] * (alpha * mu_[a]);
+        }
+        tl_last_small += 1;
+        return cut;
+      }
+    }
+  }
   const double eps = ORC_EXACT_EPS * tr;
   /* L D L^T of S + eps I (symmetric positive definite), natural order */
   double Lf[OS2R_MAX_DOF][OS2R_MAX_DOF] = {{0}}, D[OS2R_MAX_DOF];
@@ -831,7 +903,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
     int solves = 0;
-    if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; }
+    if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; tl_last_small = 0; }
     for (int it = 0; it < sweeps; ++it) {
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
@@ -1083,9 +1155,16 @@ void orc_set_contact_model(OrcSim* s, int model) { s->contact_model = model; }
 /* diagnostics: record, from now on, the phase-2 sweeps and exact solves of every physics iteration of a step */
 int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves) {
   const size_t n = (size_t)s->cfg.substeps * s->N;
-  if (!s->solver_counts) { s->solver_counts = (int8_t*)calloc(2 * n, 1); return 1; }   /* first call switches recording on */
+  if (!s->solver_counts) { s->solver_counts = (int8_t*)calloc(3 * n, 1); return 1; }   /* first call switches recording on */
   if (sweeps) memcpy(sweeps, s->solver_counts, n);
   if (solves) memcpy(solves, s->solver_counts + n, n);
+  return 0;
+}
+/* (recording on:) how many of those solves were dual solves of a small free set */
+int orc_get_small_solve_counts(OrcSim* s, int8_t* small) {
+  const size_t n = (size_t)s->cfg.substeps * s->N;
+  if (!s->solver_counts) return 1;
+  memcpy(small, s->solver_counts + 2 * n, n);
   return 0;
 }
 
@@ -1132,6 +1211,7 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
       if (s->solver_counts) {
         s->solver_counts[(size_t)k * s->N + e] = (int8_t)(tl_last_sweeps > 127 ? 127 : tl_last_sweeps);
         s->solver_counts[((size_t)cfg->substeps + k) * s->N + e] = (int8_t)(tl_last_solves > 127 ? 127 : tl_last_solves);
+        s->solver_counts[((size_t)2 * cfg->substeps + k) * s->N + e] = (int8_t)(tl_last_small > 127 ? 127 : tl_last_small);
       }
     }
     if (g_warm == 1) memcpy(s->warm + (size_t)e * ORC_WARM_SLOTS, tl_warm, sizeof tl_warm);
