@@ -83,7 +83,6 @@ constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;
 // is not cut and leaves more than kExactIncons of the squared residual it found steps on along its multipliers -- past
 // the full step -- to the first bound, and counts as cut.
 constexpr double kExactIncons = 1e-4, kExactNoBound = 1e300;
-constexpr double kSmallPivot = 1e-8;   // the dual solve of a small free set gives way to the regularised one below this pivot / diagonal
 
 // Work done by one wave in one physics iteration, for the counting kernel variants (wave-uniform values).
 struct WorkCounts {
@@ -96,8 +95,6 @@ struct WorkCounts {
   unsigned full_sincos = 0;   // 1 if some lane evaluated sin/cos in full in this iteration
   unsigned exact_solves = 0;  // exact free-set solves executed (some lane of the wave needed one)
   unsigned lane_exact_solves = 0;  // exact free-set solves x lanes that took part
-  unsigned general_solves = 0;       // of those: solves in which some lane took the regularised solve (not the dual solve of a small free set)
-  unsigned lane_general_solves = 0;  //   x lanes that took it
 };
 
 // ----------------------------------------------------------------------------------------
@@ -1343,7 +1340,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   // One exact solve of the rows strictly inside their box, every other row held at its bound.  Returns whether a
   // bound cut the step short (that row then sits on its bound and the caller solves again with the smaller set).
   // Runs under the mask of the lanes that need it; nothing in it looks at another lane.
-  auto regularised_solve = [&](auto first, bool test_consistency) -> bool {
+  auto exact_solve = [&](auto first, bool test_consistency) -> bool {
     constexpr int NT = NQ * (NQ + 1) / 2;
     auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };   // j <= i
     // Branch-free on purpose (bitwise logic on the predicates, selects, min / max): written with && / || and
@@ -1534,203 +1531,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     OS2R_ISA_MARK(14);
     return cut;
   };
-  // ---- small free sets: the dual solve (round 4) ----
-  // An environment that needs a solve has, as a rule, two free rows -- the normal and one tangential row of a contact that
-  // sticks in one direction and slides in the other, or the normals of two contacts -- seldom three, hardly ever more, and
-  // its joints slide (their friction rows sit on their bounds): measured on the bench workloads, 99.7 % of the solves
-  // (C4; C3 99.3 %).  Such a set is solved in the dual: the free contact rows are gathered into per-lane LDS slots (a lane's
-  // free rows are its own business: slot k of a lane holds its k-th free row in sweep order; the per-lane slots of the
-  // articulated-body passes are free during the solve), A = G_F G_F^T (3 x 3 at most) is factorised L D L^T in that order,
-  // mu = -A^-1 w, the step is cut at the first bound as in the regularised solve, and the impulses go back to their rows by
-  // their running index: ~350 instructions against ~950.  A lane with more than kSmall free contact rows, a free joint row
-  // or a pivot below kSmallPivot of its diagonal entry (dependent rows) takes the regularised solve -- its own decision,
-  // from its own data.  Returns whether a bound cut the step; `done` is cleared for the lanes that must take the other solve.
-  constexpr int kSmall = 3;
-  constexpr bool kSmallSolve = kStdExact && CMASK != 0u;   // (the other fp64 kernels keep their multipliers and y0 in those LDS slots)
-  auto small_solve = [&](auto first, bool& done) -> bool {
-    constexpr int kFirst = decltype(first)::value;
-    auto is_free = [](T l, T lo, T hi, bool upper) { return (l > lo) & (upper ? (l < hi) : true); };
-    constexpr int kSlotWords = 8;   // g[0..4], w, lambda, hi (inf: no upper bound; the lower bound is 0 then, -hi otherwise)
-    static_assert(kSlotWords * (kSmall + 1) <= 32, "per-lane LDS slots (os2r_kernels.hpp lds_words)");
-    auto each_contact_row = [&](auto&& f) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        if (!((CMASK >> b) & 1u)) continue;
-        if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-        const T lim = limfix[b];
-        f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(kExactNoBound), false);
-        f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true);
-        f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true);
-      }
-    };
-    // a free joint row: not this solve's business
-    bool jfree = false;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) jfree = jfree | is_free(lf[j], -fb[j], fb[j], true);
-    // gather: the k-th free contact row of a lane goes to its slot min(k, kSmall) (the last slot takes what does not fit and
-    // is never read); rows that are free in no lane at work are skipped by the wave, and remembered as such for the way back
-    int m = 0;
-    unsigned rows_touched = 0u;   // (wave-uniform) rows that are free in some lane
-    each_contact_row([&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
-      const bool fr = is_free(l, lo, hi, upper);
-      if (__ballot(fr) == 0ull) return;
-      rows_touched |= 1u << slot;
-      if (fr) {
-        T w = -target;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k)
-          if (k <= nz) w = fma_t(g[k], y[k], w);
-        const int ks = m < kSmall ? m : kSmall;
-        T* sp = lds + (ks * kSlotWords) * kWave + lane_;
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) sp[k * kWave] = k <= nz ? g[k] : T(0);
-        sp[5 * kWave] = w;
-        sp[6 * kWave] = l;
-        sp[7 * kWave] = hi;
-        m += 1;
-      }
-    });
-    done = !jfree & (m <= kSmall);
-    if (__ballot(done) == 0ull) return false;
-    // the slots come back: all of a lane's kSmall slots, those beyond its count cleaned (whatever the LDS held there)
-    T G[kSmall][NQ], w[kSmall], l0[kSmall], hi_[kSmall];
-    const bool slot2 = __ballot(done & (m > 2)) != 0ull;   // (most waves have no lane with three free rows: a slot less to fetch)
-#pragma unroll
-    for (int a = 0; a < kSmall; ++a) {
-      if (a == 2 && !slot2) {
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) G[a][k] = T(0);
-        w[a] = T(0); l0[a] = T(0); hi_[a] = T(0);
-        continue;
-      }
-      const T* sp = lds + (a * kSlotWords) * kWave + lane_;
-#pragma unroll
-      for (int k = 0; k < NQ; ++k) G[a][k] = sp[k * kWave];
-      w[a] = sp[5 * kWave]; l0[a] = sp[6 * kWave]; hi_[a] = sp[7 * kWave];
-    }
-#pragma unroll
-    for (int a = 0; a < kSmall; ++a) {
-      if (a == 2 && !slot2) continue;
-      const bool on = a < m;
-#pragma unroll
-      for (int k = 0; k < NQ; ++k) G[a][k] = on ? G[a][k] : T(0);
-      w[a] = on ? w[a] : T(0); l0[a] = on ? l0[a] : T(0); hi_[a] = on ? hi_[a] : T(0);
-    }
-    // A = G G^T (lower triangle), unit diagonal for an empty slot; L D L^T in slot order; a dependent row fails its pivot
-    auto dot = [](const T (&u)[NQ], const T (&v)[NQ]) {
-      T t = u[0] * v[0];
-#pragma unroll
-      for (int k = 1; k < NQ; ++k) t = fma_t(u[k], v[k], t);
-      return t;
-    };
-    const T a00 = 0 < m ? dot(G[0], G[0]) : T(1), a11 = 1 < m ? dot(G[1], G[1]) : T(1);
-    const T a10 = dot(G[1], G[0]);
-    const T i0 = rcp_t(a00);
-    const T l10 = opaque(a10 * i0);
-    const T d1 = fma_t(-l10, a10, a11);
-    bool ok = (a00 > T(0)) & (d1 > T(kSmallPivot) * a11);
-    const T i1 = rcp_t(d1);
-    T a22 = T(1), l20 = T(0), l21 = T(0), i2 = T(1);
-    if (slot2) {
-      a22 = 2 < m ? dot(G[2], G[2]) : T(1);
-      const T a20 = dot(G[2], G[0]), a21 = dot(G[2], G[1]);
-      l20 = opaque(a20 * i0);
-      const T u21 = fma_t(-l20, a10, a21);
-      l21 = opaque(u21 * i1);
-      const T d2 = fma_t(-l21, u21, fma_t(-l20, a20, a22));
-      ok = ok & (d2 > T(kSmallPivot) * a22);
-      i2 = rcp_t(d2);
-    }
-    done = done & ok;
-    // mu = -A^-1 w
-    T mu[kSmall];
-    mu[0] = -w[0];
-    mu[1] = fma_t(-l10, mu[0], -w[1]);
-    mu[2] = fma_t(-l21, mu[1], fma_t(-l20, mu[0], -w[2]));
-    mu[0] = opaque(mu[0] * i0); mu[1] = opaque(mu[1] * i1); mu[2] = opaque(mu[2] * i2);
-    mu[1] = fma_t(-l21, mu[2], mu[1]);
-    mu[0] = fma_t(-l10, mu[1], fma_t(-l20, mu[2], mu[0]));
-    // the largest feasible fraction of the step, the impulses (a row that the cut step takes to its bound is set on it)
-    bool cut = false;
-    T lo_[kSmall];
-    bool up_[kSmall];
-#pragma unroll
-    for (int a = 0; a < kSmall; ++a) {
-      up_[a] = hi_[a] < T(kExactNoBound);
-      lo_[a] = up_[a] ? -hi_[a] : T(0);
-      const T full = l0[a] + mu[a];
-      cut = cut | ((a < m) & ((full < lo_[a]) | (up_[a] & (full > hi_[a]))));
-    }
-    T alpha = T(1);
-    if (__ballot(done & cut) != 0ull) {
-      T a_ = T(1);
-#pragma unroll
-      for (int a = 0; a < kSmall; ++a) {
-        const bool upw = mu[a] > T(0);
-        const bool bounded = (a < m) & ((mu[a] < T(0)) | (up_[a] & upw));
-        const T room = (upw ? hi_[a] : lo_[a]) - l0[a];
-        const T lim = opaque(room * rcp_t(bounded ? mu[a] : T(1)));   // same sign as mu, so lim >= 0
-        a_ = (bounded & (lim < a_)) ? lim : a_;
-      }
-      alpha = cut ? a_ : T(1);
-    }
-    T nl[kSmall];
-#pragma unroll
-    for (int a = 0; a < kSmall; ++a) {
-      T v = fma_t(alpha, mu[a], l0[a]);
-      const bool at_hi = cut & up_[a] & (mu[a] > T(0)) & ((hi_[a] - v) <= T(kExactSnap) * (hi_[a] - l0[a]));
-      const bool at_lo = cut & (mu[a] < T(0)) & ((v - lo_[a]) <= T(kExactSnap) * (l0[a] - lo_[a]));
-      v = at_hi ? hi_[a] : v;
-      v = at_lo ? lo_[a] : v;
-      v = fmax_t(v, lo_[a]);
-      v = up_[a] ? fmin_t(v, hi_[a]) : v;
-      nl[a] = v;
-    }
-    // what follows changes the state of the lanes this solve is for, and of no other
-    if (done) {
-      // the velocity: y += alpha * G_F^T mu, slot by slot
-#pragma unroll
-      for (int a = 0; a < kSmall; ++a) {
-        if (a == 2 && !slot2) continue;
-        const T am = opaque(alpha * mu[a]);
-#pragma unroll
-        for (int k = 0; k < NQ; ++k) y[k] = fma_t(G[a][k], am, y[k]);
-      }
-      // the impulses go back to their rows through the slots they came from (a select chain over the three new values by a
-      // running index is turned into a dynamically indexed array by the compiler -- 88 B of scratch memory per lane; a
-      // dynamically addressed LDS read is what the hardware has for this): requested row by row, taken in a second pass
-#pragma unroll
-      for (int a = 0; a < kSmall; ++a) {
-        if (a == 2 && !slot2) continue;
-        lds[(a * kSlotWords + 6) * kWave + lane_] = nl[a];
-      }
-      T back[3 * NB];
-      int k_ = 0;
-      each_contact_row([&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
-        back[slot] = T(0);
-        if (!((rows_touched >> slot) & 1u)) return;
-        const bool fr = is_free(l, lo, hi, upper);
-        const int ks = k_ < kSmall ? k_ : kSmall;
-        back[slot] = lds[(ks * kSlotWords + 6) * kWave + lane_];
-        k_ += fr ? 1 : 0;
-      });
-      each_contact_row([&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
-        if (!((rows_touched >> slot) & 1u)) return;
-        l = is_free(l, lo, hi, upper) ? back[slot] : l;
-      });
-    }
-    return cut & done;
-  };
-  // One exact solve of the rows strictly inside their box: the dual solve for a small free set, the regularised one otherwise.
-  auto exact_solve = [&](auto first, bool test_consistency, bool& was_small) -> bool {
-    bool cut = false, done = false;
-    if constexpr (kSmallSolve) cut = small_solve(first, done);
-    was_small = done;
-    if (__ballot(!done) != 0ull) {
-      if (!done) cut = regularised_solve(first, test_consistency);
-    }
-    return cut;
-  };
   // Phase 2 with the exact finish: warm_first(NQ) sweeps, the last of them measured; from then on an environment that is
   // still live solves (again while a bound cuts its step short, pgs_exact solves at most per physics iteration) and
   // takes one measured sweep, until the sweep moves no more than pgs_tol or pgs_iters sweeps are spent.
@@ -1764,12 +1564,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       bool again = false;
       OS2R_STAMP(8);
       if (do_solve) {
-        bool was_small = false;
-        again = exact_solve(first, solves > 0, was_small);
-        if constexpr (COUNT) {
-          const unsigned long long gv = __ballot(!was_small);
-          if (gv != 0ull) { wc.general_solves += 1u; wc.lane_general_solves += (unsigned)__popcll(gv); }
-        }
+        again = exact_solve(first, solves > 0);
         ++solves;
         again = again && solves < pgs_exact;
       }

@@ -390,10 +390,9 @@ __device__ __forceinline__ void store_obs_tile(T* __restrict__ dst, const T (&ob
 // observation tile of the coalesced [N][D] store.
 template <int NQ>
 constexpr int lds_words() {
-  // per-lane slots: per-joint ABA data (U, 1/D, u) / the factor of Minv, and the gather slots of the dual solve of small
-  // free sets (os2r_device.hpp small_solve: 4 slots of 8 words) -- or the observation tile, if that is larger
-  constexpr int rows = NQ * (NQ + 1) / 2, aba = 8 * NQ, small = 32;
-  constexpr int m = (rows > aba ? rows : aba) > small ? (rows > aba ? rows : aba) : small;
+  // Cholesky factor of Minv / per-joint ABA data (U, 1/D, u)
+  constexpr int rows = NQ * (NQ + 1) / 2, aba = 8 * NQ;
+  constexpr int m = rows > aba ? rows : aba;
   return kWave * (m > OS2R_MAX_OBS ? m : OS2R_MAX_OBS);
 }
 // wave-shared copy of the contact candidate table, behind the per-lane slots
@@ -628,7 +627,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     if (A.counters && lane == 0) {
       const unsigned long long v[kWorkCounters] = {(unsigned long long)A.substeps * (unsigned long long)nsteps, wc.scanned, wc.row_bodies, wc.body_sweeps,
                                                     wc.sweeps, wc.lane_contacts, wc.live_lane_sweeps, wc.full_sincos,
-                                                    wc.exact_solves, wc.lane_exact_solves, wc.general_solves, wc.lane_general_solves};
+                                                    wc.exact_solves, wc.lane_exact_solves};
 #pragma unroll
       for (int k = 0; k < kWorkCounters; ++k) atomicAdd(A.counters + k, v[k]);
     }

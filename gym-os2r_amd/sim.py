@@ -249,7 +249,7 @@ class HipSim:
         sims[0]._check(rc, "os2r_bench_steps_multi")
 
     WORK_COUNTERS = ("wave_iterations", "scanned_bodies", "row_bodies", "body_sweeps", "sweeps", "lane_contacts",
-                     "live_lane_sweeps", "full_sincos", "exact_solves", "lane_exact_solves", "general_solves", "lane_general_solves")
+                     "live_lane_sweeps", "full_sincos", "exact_solves", "lane_exact_solves")
 
     def count_work(self, on: bool = True):
         """Switch the counting variant of the step kernel on (include/os2r.h: os2r_set_work_counters) or off.

@@ -323,11 +323,10 @@ OS2R_API int os2r_bench_steps_multi(Os2rSim* const* sims, void* const* streams, 
  * candidate scan ran, [2] bodies whose contact rows were set up, [3] phase-2 sweeps x bodies they covered,
  * [4] phase-2 sweeps executed, [5] (environment, body) contacts, [6] phase-2 sweeps x environments still live in
  * them, [7] wave x iterations that evaluated sin/cos in full, [8] exact free-set solves executed by waves, [9] exact
- * solves x environments that took part, [10] of those solves: the ones in which some environment took the regularised solve
- * (the others were dual solves of small free sets only), [11] regularised solves x environments.  Counting variants exist for the compiled-in robots
+ * solves x environments that took part.  Counting variants exist for the compiled-in robots
  * with ground contact, the default sweep counts and a reference task layout (OS2R_ERR_INVALID otherwise).
  * NULL switches counting off.                                                                                   */
-#define OS2R_NUM_WORK_COUNTERS 12
+#define OS2R_NUM_WORK_COUNTERS 10
 OS2R_API int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
 
 /* Done reasons (replaces the debug line that names the observation which caused a reset,

@@ -661,17 +661,20 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * ORC_EXACT_INCONS of what it found (squared norms), it goes on in the direction of its multipliers -- past the full
  * step -- to the first bound it meets, sets that row on it and solves again, as after a cut. */
 #define ORC_EXACT_INCONS 1e-4
-/* Small free sets (round 4).  In the regimes the stepper lives in, an environment that needs a solve has two free rows
- * -- the normal and one tangential row of a sticking-sliding contact, or the normals of two contacts -- seldom three and
- * hardly ever more (joints slide: their friction rows sit on their bounds).  A free set of at most ORC_EXACT_SMALL rows
- * is therefore solved in the DUAL: A mu = -w with A = G_F G_F^T (m x m, L D L^T in sweep order, no pivoting), the impulses
- * move by mu and the velocity by Minv J_F^T mu -- the same equality-constrained minimum as the regularised 5 x 5 solve
- * below, reached with a tenth of the arithmetic -- with the same cut at the first bound.  A set whose rows are (nearly)
- * dependent -- a pivot below ORC_EXACT_SMALL_PIVOT of its diagonal entry -- or larger takes the regularised solve, which
- * is made for that. */
+/* EXPERIMENT (oracle only, off by default; docs/studies/round4_solver.md): small free sets solved in the dual.  In the
+ * regimes the stepper lives in, an environment that needs a solve has two free rows -- the normal and one tangential row
+ * of a sticking-sliding contact, or the normals of two contacts -- seldom three and hardly ever more (joints slide: their
+ * friction rows sit on their bounds).  With the switch on, a free set of at most ORC_EXACT_SMALL rows is solved in the
+ * DUAL: A mu = -w with A = G_F G_F^T (m x m, L D L^T in sweep order, no pivoting), the impulses move by mu and the velocity
+ * by Minv J_F^T mu -- the same equality-constrained minimum as the regularised 5 x 5 solve below -- with the same cut at
+ * the first bound; a set whose rows are (nearly) dependent -- a pivot below ORC_EXACT_SMALL_PIVOT of its diagonal entry --
+ * or larger takes the regularised solve.  It serves 99.7 % of the solves of the bench workload and passes every exactness
+ * test; on the GPU its gather / scatter through per-lane LDS slots cost as much as the regularised solve it replaces
+ * (a wave that owns its SIMD pays per instruction, branch and LDS round trip, not per flop), so the kernels do not have
+ * it and the specification stays with the one solve. */
 #define ORC_EXACT_SMALL 3
 #define ORC_EXACT_SMALL_PIVOT 1e-8
-static int g_small = 1;   /* (orc_set_experimental_small: studies -- 0 switches the dual solve of small free sets off) */
+static int g_small = 0;   /* (orc_set_experimental_small: studies -- 1 switches the dual solve of small free sets on) */
 void orc_set_experimental_small(int on) { g_small = on; }
 static _Thread_local int tl_last_small = 0;   /* diagnostics: dual solves among the solves of the last iteration */
 

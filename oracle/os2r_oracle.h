@@ -53,7 +53,7 @@ int orc_get_small_solve_counts(OrcSim* s, int8_t* small);               /* of th
 void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
 void orc_set_experimental_row_order(int order);
 void orc_set_experimental_warm(int mode, int first);  /* studies: 1 the specification, 0 no warm start, 2 round 3 (forgotten between env-steps); K sweeps before the first check */
-void orc_set_experimental_small(int on);   /* studies: 0 switches the dual solve of small free sets off (every solve is the regularised one) */
+void orc_set_experimental_small(int on);   /* studies: 1 switches the dual solve of small free sets on (off: every solve is the regularised one) */
 int orc_get_solver_state(OrcSim* s, double* lam, uint32_t* flags);   /* layout of os2r_get_solver_state (include/os2r.h) */
 int orc_set_solver_state(OrcSim* s, const double* lam, const uint32_t* flags);
 int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);
