@@ -539,8 +539,12 @@ struct Params<T, MD, true> {
 // Diagnostic phase stamps (separate build with -DOS2R_STAMPS, never in the shipped library):
 // shader-clock ticks per phase are summed per wave and written by lane 0 to a debug buffer that
 // nothing else reads (cdna_hip_programming.md, "In-kernel stamps").
-constexpr int kStamps = 26;   // 0..11 phases, 12..23 finer marks inside the dynamics, 24/25 shader-clock and 100 MHz real-time ticks of the wave
-#ifdef OS2R_STAMPS
+constexpr int kStamps = 32;   // 0..11 phases, 12..23 finer marks inside the dynamics, 24/25 shader-clock and 100 MHz real-time ticks of the wave, 26..30 the passes of the exact solve
+#if defined(OS2R_STAMPS) && defined(OS2R_STAMPS_LIGHT)
+// the light stamp build (make stamps_light): no stamp inside the env-step -- the code of the shipped kernel -- only the wave's
+// start and end on the 100 MHz clock, its life in shader cycles and its place (tools/dbg/wave_times.py: who ends a launch, and when)
+#define OS2R_STAMP(idx) do { } while (0)
+#elif defined(OS2R_STAMPS)
 #define OS2R_STAMP(idx)                                                                        \
   do {                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -1337,6 +1341,28 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
     for (int j = 0; j < NQ; ++j) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true);
   };
+  // The same, visiting only the rows whose bit is set in the wave-uniform mask U (bit 3b + t: row t of body b, bit 3 NB + j:
+  // joint j) -- a body none of whose rows is in U, and the joint rows when none of them is, are passed over with ONE branch:
+  // a wave that owns its SIMD pays ~45 cycles for every taken branch, more than for the test itself (round 4: the solve's
+  // fourteen rows times four passes were 56 skip decisions, most of them taken)
+  auto each_row_in = [&](auto first, unsigned U, auto&& f) {
+    constexpr int kFirst = decltype(first)::value;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!((CMASK >> b) & 1u)) continue;
+      if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
+      if (((U >> (3 * b)) & 7u) == 0u) continue;
+      const T lim = limfix[b];
+      if ((U >> (3 * b + 0)) & 1u) f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(0), false);
+      if ((U >> (3 * b + 1)) & 1u) f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true);
+      if ((U >> (3 * b + 2)) & 1u) f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true);
+    }
+    if (((U >> (3 * NB)) & ((1u << NQ) - 1u)) != 0u) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+        if ((U >> (3 * NB + j)) & 1u) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true);
+    }
+  };
   // One exact solve of the rows strictly inside their box, every other row held at its bound.  Returns whether a
   // bound cut the step short (that row then sits on its bound and the caller solves again with the smaller set).
   // Runs under the mask of the lanes that need it; nothing in it looks at another lane.
@@ -1363,13 +1389,19 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     auto mu_put = [&](int slot, T v) { if constexpr (kMuInLds) L(kMuSlot + slot) = v; else mu_reg[slot] = v; };
     auto mu_get = [&](int slot) -> T { if constexpr (kMuInLds) return L(kMuSlot + slot); else return mu_reg[slot]; };
     OS2R_ISA_MARK(9);
+    OS2R_STAMP(8);    // (what precedes a solve inside the loop stays with the sweeps)
+    // which rows are free for some lane at work here (two or three of the 64, typically, with two free rows each): found once
+    // per solve -- the impulses do not move before the last pass -- branch-free, kept as one scalar bit mask
+    unsigned U = 0u;
+    each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
+      U |= __ballot(is_free(l, lo, hi, upper)) != 0ull ? (1u << slot) : 0u;
+    });
     // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
     // A row that is free for none of the lanes at work here -- typically two or three of the 64 -- adds exact zeros to S
     // and h, has mu = 0 and keeps its impulse: the wave skips it in every pass (void for every lane, so a lane's result
     // does not depend on its company).
-    each_row(first, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
+    each_row_in(first, U, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
       const bool fr = is_free(l, lo, hi, upper);
-      if (__ballot(fr) == 0ull) return;
       // the row's weight as a number the optimiser cannot see through: it would turn the products below back into
       // selects of every entry (two v_cndmask per double) or into a branch around the row
       const T f = opaque(fr ? T(1) : T(0));
@@ -1389,6 +1421,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       }
     });
     OS2R_ISA_MARK(10);
+    OS2R_STAMP(26);   // pass 1: S, h
     T tr = T(0);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) tr += S[tri(i, i)];
@@ -1446,6 +1479,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       for (int i = 0; i < NQ; ++i) { d[i] = z[i]; ds[i] = it == 0 ? z[i] : ds[i] + z[i]; }
     }
     OS2R_ISA_MARK(11);
+    OS2R_STAMP(27);   // factorisation + proximal solves
     // pass 2: impulses of the free rows from the residuals, mu = -(K w + g.ds) / eps, and whether the full step
     // would take a row out of its box
     const T ieps = -rcp_t(eps);
@@ -1453,9 +1487,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // (the variant that also measures the residuals before and after the step runs when a lane of the wave asks for it)
     T found = T(0), left = T(0);
     auto pass2 = [&](auto measure_) {
-      each_row(first, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
+      each_row_in(first, U, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
         const bool fr = is_free(l, lo, hi, upper);
-        if (__ballot(fr) == 0ull) { mu_put(slot, T(0)); return; }   // (the full step below adds it without asking)
         const T f = opaque(fr ? ieps : T(0));
         T w = -target;
 #pragma unroll
@@ -1484,13 +1517,13 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     else pass2(std::false_type{});
     const bool incons = test_consistency & !cut & (left > T(kExactIncons) * found);
     OS2R_ISA_MARK(12);
+    OS2R_STAMP(28);   // pass 2: impulses, cut test
     // the largest feasible fraction of the step: the wave computes it when one of its lanes needs it, and only the lanes
     // whose full step leaves a box take it
     T alpha = T(1);
     if (__ballot(cut | incons) != 0ull) {
       T a = incons ? T(kExactNoBound) : T(1);
-      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
-        if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
+      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         const T m = mu_get(slot);
         const bool up = m > T(0);
         const bool bounded = (m < T(0)) | (upper ? up : false);
@@ -1502,13 +1535,13 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       alpha = cut ? a : T(1);
     }
     OS2R_ISA_MARK(13);
+    OS2R_STAMP(29);   // step length
     // the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
     // that the cut step has taken to its bound (the room left is below kExactSnap of what it had) is set on it
 #pragma unroll
     for (int i = 0; i < NQ; ++i) y[i] = fma_t(alpha, d[i], y[i]);
     if (__ballot(cut) != 0ull) {
-      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
-        if (__ballot(is_free(l, lo, hi, upper)) == 0ull) return;
+      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         const T m = mu_get(slot);
         T nl = fma_t(alpha, m, l);
         const bool at_hi = cut & (upper ? ((m > T(0)) & ((hi - nl) <= T(kExactSnap) * (hi - l))) : false);
@@ -1520,8 +1553,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         l = nl;
       });
     } else {
-      // (no test: a row that is not free has the multiplier 0 and sits inside its box)
-      each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
+      // (a row of U that is not free for this lane has the multiplier 0 and sits inside its box)
+      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
         T nl = l + mu_get(slot);
         nl = fmax_t(nl, lo);
         if (upper) nl = fmin_t(nl, hi);
@@ -1529,6 +1562,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       });
     }
     OS2R_ISA_MARK(14);
+    OS2R_STAMP(30);   // apply
     return cut;
   };
   // Phase 2 with the exact finish: warm_first(NQ) sweeps, the last of them measured; from then on an environment that is

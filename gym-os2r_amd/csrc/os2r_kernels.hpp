@@ -638,7 +638,19 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   // the wave's life in shader-clock ticks and in ticks of the constant 100 MHz counter: their quotient is the clock
   // the chip held under this load (MI355X_MICROARCH.md, DVFS give-back (6))
   stamps[24] = __builtin_amdgcn_s_memtime() - stamp_entry;
-  stamps[25] = __builtin_amdgcn_s_memrealtime() - real_entry;
+  const unsigned long long real_exit = __builtin_amdgcn_s_memrealtime();
+  stamps[25] = real_exit - real_entry;
+#ifdef OS2R_STAMPS_LIGHT
+  stamps[22] = real_entry;   // absolute: comparable between the waves of a launch
+  stamps[23] = real_exit;
+  {
+    unsigned hw_id;            // where the wave ran: XCC_ID / SE / CU / SIMD fields of HW_ID and XCC_ID
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    stamps[21] = ((unsigned long long)xcc << 32) | hw_id;
+  }
+#endif
   if (A.debug && lane == 0)
     for (int k = 0; k < kStamps; ++k) A.debug[blockIdx.x * kStamps + k] = stamps[k];
 #endif

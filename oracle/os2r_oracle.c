@@ -36,6 +36,7 @@
  * kernels use hand-specialised sparse forms, so agreement is a meaningful check.
  */
 #define _GNU_SOURCE
+#include <stdio.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -629,6 +630,49 @@ static int block_update(int n, Row* rows, int r0, double* v, double* moved) {
   return 1;
 }
 
+/* The block update a kernel can afford (experiment; g_block_kind == 1): one Gauss-Seidel pass over the three rows in
+ * impulse space (the block's Gram matrix A = G G^T, residuals w), then ONE exact solve of the rows that pass left strictly
+ * inside their box, the others held where the pass put them; the result is taken if it stays inside the box, else the
+ * pass stands.  Exact whenever the pass identifies the block's active set, which a warm start nearly always does. */
+static int g_block_kind = 0;
+void orc_set_experimental_block_kind(int kind) { g_block_kind = kind; }
+static int block_update_cheap(int n, Row* rows, int r0, double* v, double* moved) {
+  Row* R[3] = {&rows[r0], &rows[r0 + 1], &rows[r0 + 2]};
+  for (int i = 0; i < 3; ++i) if (!(R[i]->d > 0.0)) return 0;
+  double A[3][3], w[3], w0[3], lam[3], l0[3], lo[3], hi[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += R[i]->J[k] * R[j]->T[k]; A[i][j] = s; }
+    double s = -R[i]->target; for (int k = 0; k < n; ++k) s += R[i]->J[k] * v[k];
+    w[i] = s; w0[i] = s; lam[i] = R[i]->lambda; l0[i] = lam[i];
+  }
+  lo[0] = 0.0; hi[0] = INFINITY;
+  for (int i = 1; i < 3; ++i) { hi[i] = R[i]->bound; lo[i] = -hi[i]; }
+  int fr[3];
+  for (int i = 0; i < 3; ++i) {
+    double nl = lam[i] - w[i] / A[i][i];
+    if (nl < lo[i]) nl = lo[i];
+    if (nl > hi[i]) nl = hi[i];
+    const double dl = nl - lam[i];
+    lam[i] = nl;
+    for (int j = 0; j < 3; ++j) w[j] += A[j][i] * dl;
+  }
+  int idx[3], m = 0;
+  for (int i = 0; i < 3; ++i) { fr[i] = lam[i] > lo[i] && lam[i] < hi[i]; if (fr[i]) idx[m++] = i; }
+  double mu[3] = {0, 0, 0};
+  if (m > 0 && solve_sub(A, w, idx, m, mu)) {
+    int ok = 1;
+    for (int i = 0; i < 3; ++i) if (fr[i]) { const double t = lam[i] + mu[i]; if (t < lo[i] || t > hi[i]) ok = 0; }
+    if (ok) for (int i = 0; i < 3; ++i) if (fr[i]) lam[i] += mu[i];
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double dl = lam[i] - l0[i];
+    R[i]->lambda = lam[i];
+    *moved += fabs(w0[i]) * fabs(dl);
+    for (int k = 0; k < n; ++k) v[k] += R[i]->T[k] * dl;
+  }
+  return 1;
+}
+
 /* EXPERIMENT (oracle only, off by default): order of the three rows of a contact inside a phase-2 sweep.
  * 0: normal, x, y (the specification)   1: y, x, normal   2: the less mobile tangential row, the other, normal */
 static int g_row_order = 0;
@@ -674,6 +718,8 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * it and the specification stays with the one solve. */
 #define ORC_EXACT_SMALL 3
 #define ORC_EXACT_SMALL_PIVOT 1e-8
+static int g_clamp_all = 0;
+void orc_set_experimental_clamp_all(int on) { g_clamp_all = on; }
 static int g_small = 0;   /* (orc_set_experimental_small: studies -- 1 switches the dual solve of small free sets on) */
 void orc_set_experimental_small(int on) { g_small = on; }
 static _Thread_local int tl_last_small = 0;   /* diagnostics: dual solves among the solves of the last iteration */
@@ -696,6 +742,33 @@ static void row_box(const Row* rows, const Row* R, int fixed_box, double* lo, do
   if (R->kind == 0) { *lo = 0.0; *hi = INFINITY; }
   else if (R->kind == 1) { *hi = fixed_box ? R->bound : R->bound * rows[R->normal_row].lambda; *lo = -*hi; }
   else { *hi = R->bound; *lo = -*hi; }
+}
+
+/* diagnostics (ORC_TRACE_SOLVES=k in the environment: iterations with k or more solves are printed, solve by solve:
+ * the free set by row kind -- n normal, t tangential, j joint, lower case; upper case = the row the step ended on) */
+static int g_trace = -1;
+static _Thread_local char tl_trace[4096];
+static _Thread_local int tl_trace_len = 0;
+static void trace_sweep(double moved) {
+  if (g_trace <= 0) return;
+  char* b = tl_trace + tl_trace_len; char* e = tl_trace + sizeof(tl_trace) - 8;
+  if (b >= e) return;
+  b += snprintf(b, (size_t)(e - b), " E=%.2g", moved);
+  tl_trace_len = (int)(b - tl_trace);
+}
+static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu, double alpha, int cut, int incons, int nviol, double found, double left) {
+  if (g_trace <= 0) return;
+  char* b = tl_trace + tl_trace_len; char* e = tl_trace + sizeof(tl_trace) - 8;
+  if (b >= e) return;
+  *b++ = ' '; *b++ = '[';
+  for (int r = 0; r < nr && b < e; ++r) {
+    if (!(rows[r].d > 0.0)) { *b++ = '.'; continue; }
+    char c = rows[r].kind == 0 ? 'n' : (rows[r].kind == 1 ? 't' : 'j');
+    if (!fr[r]) { double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi); *b++ = rows[r].lambda <= lo ? '-' : '+'; continue; }
+    *b++ = c;
+  }
+  b += snprintf(b, (size_t)(e - b), "] a=%.3g%s%s v%d f=%.1e l=%.1e", alpha, cut ? " cut" : "", incons ? " incons" : "", nviol, found, left);
+  tl_trace_len = (int)(b - tl_trace);
 }
 
 /* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
@@ -825,6 +898,26 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
       if (lim < alpha) alpha = lim;
     }
   if (on) { if (isfinite(alpha)) cut = 1; else alpha = 1.0; }
+  if (g_trace > 0) {
+    int nviol = 0;
+    for (int r = 0; r < nr; ++r) if (fr[r]) { double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi); const double full = rows[r].lambda + mu[r]; nviol += full < lo || full > hi; }
+    trace_solve(rows, nr, fr, mu, alpha, cut, on, nviol, found, left);
+  }
+  if (g_clamp_all && cut && !on) {
+    /* EXPERIMENT: a step that a bound cuts short is taken in full, every row clamped into its own box (all violators are
+     * set on their bounds at once, a primal-dual active-set step), the velocity following row by row */
+    for (int r = 0; r < nr; ++r) {
+      if (!fr[r]) continue;
+      double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+      double nl = rows[r].lambda + mu[r];
+      if (nl < lo) nl = lo;
+      if (nl > hi) nl = hi;
+      const double dl = nl - rows[r].lambda;
+      rows[r].lambda = nl;
+      for (int j = 0; j < n; ++j) v[j] += rows[r].T[j] * dl;
+    }
+    return 1;
+  }
   /* the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
    * that the cut step has taken to its bound (the room left is below ORC_EXACT_SNAP of what it had) is set on it */
   for (int i = 0; i < n; ++i) { double s = 0; for (int k = 0; k <= i; ++k) s += lc[i * n + k] * d[k]; v[i] += alpha * s; }
@@ -861,7 +954,15 @@ static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 #define ORC_WARM_FIRST 3
 #define ORC_WARM_ROWS (3 * OS2R_MAX_DOF + OS2R_MAX_DOF)
 #define ORC_WARM_SLOTS (ORC_WARM_ROWS + 1)   /* the last slot: 1.0 once an iteration has left its impulses (the joint rows are remembered) */
+static long long g_dbg_counter[4];   /* diagnostics (orc_debug_counter): [0] warm-started iterations, [1] of those with an active row that has no remembered impulse */
+long long orc_debug_counter(int which, int reset) { long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
+static int g_lag_box = 0;   /* (orc_set_experimental_lag_box: studies -- 1: the lagged friction box, docs/studies/round4_solver.md) */
+void orc_set_experimental_lag_box(int on) { g_lag_box = on; }
 static int g_warm = 1, g_first = ORC_WARM_FIRST, g_solve_always = 0;
+static int g_sweep_after_cut = 0;   /* experiment: a step that a bound cut short is followed by a sweep (which may clamp several rows at once), not by the next solve */
+void orc_set_experimental_sweep_after_cut(int on) { g_sweep_after_cut = on; }
+static int g_max_rounds = 0, g_stop_at_cap = 0;   /* experiment: an environment ends phase 2 after that many (solves, re-test sweep) rounds / when its solves are spent */
+void orc_set_experimental_rounds(int max_rounds, int stop_at_cap) { g_max_rounds = max_rounds; g_stop_at_cap = stop_at_cap; }
 /* first > 0: that many sweeps before the first check; first = -k: k - 1 sweeps, then EVERY environment solves once before its first check */
 void orc_set_experimental_warm(int mode, int first) {
   g_warm = mode; g_first = first > 0 ? first : (first < 0 ? -first - 1 : ORC_WARM_FIRST); g_solve_always = first < 0;
@@ -890,10 +991,32 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
   const int cold_now = g_warm == 0 || tl_cold;
   double lc[OS2R_MAX_DOF * OS2R_MAX_DOF];
   if (exact > 0) chol_lower(n, minv, lc);
+  /* EXPERIMENT (oracle only, off by default; built into the kernels in round 4, measured and backed out:
+   * docs/studies/round4_solver.md): the lagged friction box.  An environment whose solver state covers every row that is
+   * active now -- the joints, and every body in contact had a contact in the last iteration too -- runs no phase 1: the box
+   * of a remembered contact is mu times the normal impulse that ended the environment's last iteration, and phase 2 starts
+   * from the remembered impulses.  An environment with a FRESH row (a body that has just touched down, the iteration
+   * after a reset) runs the normal sweeps for all its rows; its fresh contacts take their box from them. */
+  const int remembers = exact > 0 && normal_iters > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS && g_lag_box;
+  int fresh = 1;
+  if (remembers) {
+    fresh = isnan(tl_warm[ORC_WARM_ROWS]);
+    for (int r = 0; r < nr; ++r) if (rows[r].kind == 0 && rows[r].d > 0.0 && isnan(tl_warm[warm_slot(rows, r)])) fresh = 1;
+  }
   for (int phase = 0; phase < 2; ++phase) {
-    const int sweeps = phase == 0 ? normal_iters : iters;
+    const int sweeps = phase == 0 ? (fresh ? normal_iters : 0) : iters;
     if (phase == 1 && normal_iters > 0)
-      for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) rows[r].bound *= rows[rows[r].normal_row].lambda;
+      for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) {
+        const int nrow = rows[r].normal_row;
+        const double mem = remembers ? tl_warm[warm_slot(rows, nrow)] : NAN;
+        rows[r].bound *= isnan(mem) ? rows[nrow].lambda : mem;
+      }
+    if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS) {
+      int fresh = 0;   /* diagnostics: an active row without a remembered impulse (a new contact, the iteration after a reset) */
+      for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0 && isnan(tl_warm[warm_slot(rows, r)])) fresh = 1;
+      __atomic_fetch_add(&g_dbg_counter[0], 1, __ATOMIC_RELAXED);
+      if (fresh) __atomic_fetch_add(&g_dbg_counter[1], 1, __ATOMIC_RELAXED);
+    }
     if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS)
       for (int r = 0; r < nr; ++r) {
         Row* R = &rows[r];
@@ -905,23 +1028,25 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         R->lambda = nl;
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
-    int solves = 0;
-    if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; tl_last_small = 0; }
+    int solves = 0, rounds = 0;
+    if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; tl_last_small = 0; tl_trace_len = 0; }
+    if (g_trace < 0) { const char* t = getenv("ORC_TRACE_SOLVES"); g_trace = t ? atoi(t) : 0; }
     for (int it = 0; it < sweeps; ++it) {
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
       if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST(n) && solves < exact) {
         int blocked = 1;
-        while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; }
+        while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; if (g_sweep_after_cut) break; }
         tl_last_solves = solves;
+        ++rounds;
       }
       if (phase == 1) tl_last_sweeps = it + 1;
       double moved = 0.0;
       for (int ri = 0; ri < nr; ++ri) {
         const int r = (phase == 1 && !g_block_solve) ? order[ri] : ri;
         Row* R = &rows[r];
-        if (g_block_solve && phase == 1 && normal_iters > 0 && R->kind == 0 && r + 2 < nr && rows[r + 1].kind == 1 &&
-            rows[r + 2].kind == 1 && block_update(n, rows, r, v, &moved)) { ri += 2; continue; }
+        if (g_block_solve && (g_block_solve == 1 || it < g_block_solve - 1) && phase == 1 && normal_iters > 0 && R->kind == 0 && r + 2 < nr && rows[r + 1].kind == 1 &&
+            rows[r + 2].kind == 1 && (g_block_kind ? block_update_cheap(n, rows, r, v, &moved) : block_update(n, rows, r, v, &moved))) { ri += 2; continue; }
         if (!(R->d > 0.0)) continue;
         if (phase == 0 && R->kind == 1) continue;
         double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
@@ -934,10 +1059,13 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         moved += fabs(res) * fabs(dl);
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
+      if (phase == 1) trace_sweep(moved);
+      if (phase == 1 && exact > 0 && g_max_rounds > 0 && (rounds >= g_max_rounds || (g_stop_at_cap && solves >= exact))) break;   /* experiment: bounded rounds */
       if (phase == 1 && it + 1 < sweeps && moved <= tol) {
         if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) && !(g_solve_always && solves == 0) : (it + 1) % ORC_PGS_GROUP == 0) break;
       }
     }
+    if (phase == 1 && g_trace > 0 && solves >= g_trace) { tl_trace[tl_trace_len] = 0; fprintf(stderr, "solves %d sweeps %d:%s\n", solves, tl_last_sweeps, tl_trace); }
     if (phase == 1 && exact > 0 && g_warm && nr <= ORC_WARM_ROWS) {
       warm_forget(tl_warm);
       for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0) tl_warm[warm_slot(rows, r)] = rows[r].lambda;

@@ -52,6 +52,12 @@ int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves);   /* diagn
 int orc_get_small_solve_counts(OrcSim* s, int8_t* small);               /* of those solves: the dual solves of small free sets */
 void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
 void orc_set_experimental_row_order(int order);
+void orc_set_experimental_rounds(int max_rounds, int stop_at_cap);
+long long orc_debug_counter(int which, int reset);   /* diagnostics, see os2r_oracle.c */
+void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged friction box (no phase 1 for an environment that remembers every active row) */
+void orc_set_experimental_sweep_after_cut(int on);
+void orc_set_experimental_clamp_all(int on);
+void orc_set_experimental_block_kind(int kind);   /* 0: enumeration of the block's active sets, 1: Gauss-Seidel pass + one exact solve of the rows left free */
 void orc_set_experimental_warm(int mode, int first);  /* studies: 1 the specification, 0 no warm start, 2 round 3 (forgotten between env-steps); K sweeps before the first check */
 void orc_set_experimental_small(int on);   /* studies: 1 switches the dual solve of small free sets on (off: every solve is the regularised one) */
 int orc_get_solver_state(OrcSim* s, double* lam, uint32_t* flags);   /* layout of os2r_get_solver_state (include/os2r.h) */

@@ -19,8 +19,10 @@ import bench
 PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y)", "contact: forward kinematics",
           "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "prologue (once per env-step)", "epilogue: state stores (once per env-step)",
           "  dyn: body velocities", "  dyn: inward body 4", "  dyn: inward body 3", "  dyn: inward body 2", "  dyn: inward body 1",
-          "  dyn: inward body 0", "PGS phase 2: exact solves", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)"]
-NS = 26   # kStamps in os2r_device.hpp
+          "  dyn: inward body 0", "PGS phase 2: exact solves", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)",
+          "  exact solve: pass 1 (S, h)", "  exact solve: factorisation + proximal solves", "  exact solve: pass 2 (impulses, cut test)", "  exact solve: step length", "  exact solve: apply"]
+COLS = list(range(24)) + list(range(26, 31))   # the columns that are phases (24 / 25: the wave's life on the two clocks)
+NS = 32   # kStamps in os2r_device.hpp
 
 
 def main():
@@ -46,12 +48,12 @@ def main():
         torch.cuda.synchronize()
         per_wave = buf.cpu().numpy().reshape(nwg, NS)
         acc += per_wave.mean(axis=0)
-        tot_w = per_wave[:, :24].sum(axis=1)
+        tot_w = per_wave[:, COLS].sum(axis=1)
         totals.append(tot_w.copy())
         spread = (tot_w.min(), tot_w.mean(), tot_w.max(), tot_w.std(), np.percentile(tot_w, 50), np.percentile(tot_w, 99))
     acc /= 20
     ghz = float(np.median(per_wave[:, 24] / np.maximum(per_wave[:, 25], 1)) * 0.1)
-    acc = acc[:24]
+    acc = acc[COLS]
     ms = sim.bench_steps(200) / 200
     print(f"stamp build: {ms * 1e3:.1f} us per env-step launch -> {ms * 1e6 / acc.sum():.3f} ns per tick of the stamped part")
     print(f"in-kernel clock: {ghz:.3f} GHz (median over waves of s_memtime / s_memrealtime x 100 MHz, last of 20 stamped launches after the pre-roll)")
@@ -69,11 +71,11 @@ def main():
 
 def tail_report(per_wave, totals, substeps):
     """What the slowest waves of the last stamped launch did differently, and whether a slow wave stays slow."""
-    tot = per_wave[:, :24].sum(axis=1)
+    tot = per_wave[:, COLS].sum(axis=1)
     order = np.argsort(-tot)
-    mean = per_wave[:, :24].mean(axis=0)
+    mean = per_wave[:, COLS].mean(axis=0)
     k = max(len(tot) // 100, 1)
-    top = per_wave[order[:k], :24].mean(axis=0)
+    top = per_wave[np.ix_(order[:k], COLS)].mean(axis=0)
     print(f"slowest {k} waves of the last launch against the mean wave ({top.sum():.0f} vs {mean.sum():.0f} ticks): the difference by phase")
     diff = top - mean
     for i in np.argsort(-diff)[:8]:

@@ -13,7 +13,8 @@ for lv in $LIBS; do
   export OS2R_LIBRARY=$ROOT/$lib
   for grp in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_WAVES" \
              "SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_WAVES" \
-             "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_WAVES"; do
+             "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_WAVES" \
+             "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES"; do
     rm -rf "$OUT/pmc_tmp"
     timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_tmp" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-count --steps 200 --warmup 20 "$@" > "$OUT/$label.log" 2>&1
     python3 - "$OUT/pmc_tmp" "$label" <<'PY' | tee -a "$OUT/pmc_table.txt"
