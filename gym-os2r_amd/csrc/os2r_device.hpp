@@ -846,12 +846,13 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 
   // ---- 2c. accelerations, outward; the base accelerates by -g (gravity as a fictitious force) ----
   T vs[NQ];  // predicted velocity v* = qd + dt*qdd
+  // the inward pass's hand-over (u, U, 1/D) of joint i + 1 is requested while joint i is worked on: a lone
+  // wave sits out every LDS round trip that is requested where it is needed.  (Declared out here: what arrived for the
+  // last joint is what the unit-torque sweep of step 3 starts with.)
+  T hu[2], hd[2];
+  V3<T> hua[2], hul[2];
   {
     V3<T> aa = mk<T>(0, 0, 0), al = mk<T>(0, 0, -par.gravity());
-    // the inward pass's hand-over (u, U, 1/D) of joint i + 1 is requested while joint i is worked on: a lone
-    // wave sits out every LDS round trip that is requested where it is needed
-    T hu[2], hd[2];
-    V3<T> hua[2], hul[2];
     auto request = [&](int i, int b) { hu[b] = L(kU + i); hua[b] = ldv(kUa, i); hul[b] = ldv(kUl, i); hd[b] = L(kDi + i); };
     auto arrived = [&](int b) {
       asm volatile("" : "+v"(hu[b]), "+v"(hd[b]), "+v"(hua[b].x), "+v"(hua[b].y), "+v"(hua[b].z), "+v"(hul[b].x), "+v"(hul[b].y), "+v"(hul[b].z));
@@ -897,11 +898,29 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     T uk[NQ][NQ];            // uk[k][i]: joint-space force of column k at joint i (i <= k)
     V3<T> pn_[NQ], pf_[NQ];  // bias force of column k, expressed in the current body
     // inward: bodies NQ-1 .. 0; all columns are swept together, so every joint rotation, U_i and 1/D_i
-    // is fetched once
+    // is fetched once -- and a body ahead of its use (round 4): left to the compiler the seven LDS reads of a body sat
+    // right in front of their first use, and a lone wave waited out every round trip (five times ~100 cycles per iteration)
+    V3<T> mUa[2], mUl[2];
+    T mdi[2];
+    auto request_m = [&](int i, int b) { mUa[b] = ldv(kUa, i); mUl[b] = ldv(kUl, i); mdi[b] = L(kDi + i); };
+    auto arrived_m = [&](int b) {
+      asm volatile("" : "+v"(mdi[b]), "+v"(mUa[b].x), "+v"(mUa[b].y), "+v"(mUa[b].z), "+v"(mUl[b].x), "+v"(mUl[b].y), "+v"(mUl[b].z));
+      asm volatile("" ::: "memory");
+    };
+    // (the last joint's U and 1/D are still in the registers of the outward pass above.  fp64 only: the fp32 kernels are
+    // built for two waves per SIMD, which hide the round trips, and have no registers to spare)
+    constexpr bool kAhead = sizeof(T) == 8;
+    if constexpr (kAhead) { mUa[(NQ - 1) & 1] = hua[(NQ - 1) & 1]; mUl[(NQ - 1) & 1] = hul[(NQ - 1) & 1]; mdi[(NQ - 1) & 1] = hd[(NQ - 1) & 1]; }
 #pragma unroll
     for (int i = NQ - 1; i >= 0; --i) {
-      const V3<T> Ua = ldv(kUa, i), Ul = ldv(kUl, i);
-      const T di = L(kDi + i);
+      if constexpr (kAhead) {
+        if (i < NQ - 1) arrived_m(i & 1);
+        if (i > 0) { request_m(i - 1, (i - 1) & 1); __builtin_amdgcn_sched_barrier(kPinDs); }
+      } else {
+        request_m(i, i & 1);
+      }
+      const V3<T> Ua = mUa[i & 1], Ul = mUl[i & 1];
+      const T di = mdi[i & 1];
       // column i starts here with a unit torque
       uk[i][i] = T(1);
       // columns k > i arrive from body i+1: express in body i, project on the joint

@@ -16,9 +16,18 @@ are all in the window, so the regressors vary); `counts` repeats them with the c
 counters back after every launch; `fit` aligns the two by launch index and solves, per workload,
       64 * (2*FMA + MUL + ADD)_launch  =  k_launch_wave * waves + k_scanned_body * scanned + k_row_body * rows
                                           + k_body_sweep * body_sweeps + k_sweep * sweeps + k_exact_solve * exact_solves
-by non-negative least squares (PMC counts wave-instructions; a wave-instruction is priced as 64 lane operations whatever its
-exec mask: issued flops).  The physics-iteration count per launch is fixed (10), so its price is inside
-k_launch_wave.  The report gives the residual of the fit per launch.
+(PMC counts wave-instructions; a wave-instruction is priced as 64 lane operations whatever its exec mask: issued flops).
+The physics-iteration count per launch is fixed (10), so its price is inside k_launch_wave.
+
+Round 4: the split is made identifiable.  In the steady state sweeps, rows and solves move together
+and a free non-negative least squares put the sweeps' flops into `launch_wave` (priced `sweep` = `body_sweep` = 0).  The
+two sweep units are therefore FIXED from the operation count of the source (os2r_device.hpp: contact_row / joint_rows --
+a row with nz non-zeros is nz FMA for the residual, one FMA for the impulse, one ADD for its change, nz FMA for the update;
+a joint row starts its residual with a MUL), times 64 lanes:
+      k_sweep      = 64 * sum over the joints j of (4 (j + 1) + 2)               (the joint-friction rows of one sweep)
+      k_body_sweep = 64 * mean over the bodies that can touch of 3 (4 (b + 1) + 3)   (the three rows of one contact)
+and only launch_wave, scanned_body, row_body and exact_solve are fitted (non-negative least squares on what the fixed
+units leave).  `fit` refuses a result that prices a solver unit at zero while its counter is not, and reports the residual.
 """
 import argparse
 import csv
@@ -69,6 +78,23 @@ def main():
         fit(a.paths[0], a.paths[1])
 
 
+def sweep_prices(workload, nbodies=None):
+    """(lane-flops of the joint rows of one phase-2 sweep, of the three rows of one contact in one sweep) x 64 lanes, from the
+    operation count of os2r_device.hpp (contact_row, joint_rows) for the robot of the workload; the contact price is the mean
+    over the `nbodies` most distal bodies that can touch (the links that lie on the ground in the steady state; default: all)"""
+    import bench
+    import gym_os2r_amd as g
+    mode = bench.WORKLOADS[workload][0]
+    model = g.get_model(g.config.SettingsConfig().get_config(f"task_modes/{mode}/model"))
+    nq = len(model["mass"])
+    bodies = sorted({int(b) for b in model["cand_body"]})
+    if nbodies:
+        bodies = bodies[-int(nbodies):]
+    joint = sum(4 * (j + 1) + 2 for j in range(nq))
+    contact = sum(3 * (4 * (b + 1) + 3) for b in bodies) / max(len(bodies), 1)
+    return 64.0 * joint, 64.0 * contact
+
+
 def pmc_per_launch(d):
     """{counter: [value per step-kernel dispatch, in dispatch order]} from a rocprofv3 --pmc output directory"""
     acc = {}
@@ -95,18 +121,27 @@ def fit(src, dst):
         waves = (counts["envs"] + 63) // 64
         X = np.array([[waves, c["scanned_bodies"], c["row_bodies"], c["body_sweeps"], c["sweeps"], c.get("exact_solves", 0)] for c in L[:n]], dtype=float)
         from scipy.optimize import nnls
-        scale = np.maximum(X.max(axis=0), 1.0)
-        k, _ = nnls(X / scale, y)          # prices cannot be negative (the regressors are correlated in time)
-        k = k / scale
+        # the sweep units from the source's operation count (see the header); the model of the workload gives the bodies
+        in_form = int(round(float(np.median(X[-200:, 2])) / (waves * 10.0)))     # bodies with rows per wave and iteration, steady state
+        k_sweep, k_body = sweep_prices(wl, max(in_form, 1))
+        fixed = k_body * X[:, 3] + k_sweep * X[:, 4]
+        free = [0, 1, 2, 5]
+        Xf = X[:, free]
+        scale = np.maximum(Xf.max(axis=0), 1.0)
+        kf, _ = nnls(Xf / scale, np.maximum(y - fixed, 0.0))          # prices cannot be negative (the regressors are correlated in time)
+        kf = kf / scale
+        k = np.array([kf[0], kf[1], kf[2], k_body, k_sweep, kf[3]])
         res = (X @ k - y) / y
         names = ["launch_wave", "scanned_body", "row_body", "body_sweep", "sweep", "exact_solve"]
+        for j, nm in enumerate(names):
+            assert not (nm in ("body_sweep", "sweep", "exact_solve") and k[j] <= 0.0 and X[:, j].sum() > 0), f"{wl}: unit {nm} priced 0 while its counter is not"
         out[wl + "_f64"] = {"flops_per_unit": dict(zip(names, k.tolist()), wave_iteration=0.0),
                             "fit": {"launches": int(n), "rel_residual_rms": float(np.sqrt((res ** 2).mean())),
                                     "rel_residual_max": float(np.abs(res).max()),
                                     "flops_per_env_step_first_20": float(y[:20].mean() / counts["envs"]),
                                     "flops_per_env_step_last_200": float(y[-200:].mean() / counts["envs"])},
-                            "source": f"profiles/flop_model.json[{wl}_f64]: least squares of 64*(2*FMA+MUL+ADD) (rocprofv3 --pmc, per launch) "
-                                      f"on the work counters of the same {n} launches from the reset"}
+                            "source": f"profiles/flop_model.json[{wl}_f64]: sweep units from the source's operation count, the others by least squares of 64*(2*FMA+MUL+ADD) "
+                                      f"(rocprofv3 --pmc, per launch) on the work counters of the same {n} launches from the reset"}
         md.append(f"## {wl} (f64, {counts['envs']} envs, {n} launches from the reset)\n")
         md.append("| unit | lane-flops per unit |\n|---|---|\n" + "".join(f"| {a} | {b:.1f} |\n" for a, b in zip(names, k)))
         md.append(f"\nrelative residual per launch: rms {np.sqrt((res ** 2).mean()):.2e}, max {np.abs(res).max():.2e}; PMC flops per env-step: "
