@@ -771,6 +771,7 @@ static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu
   tl_trace_len = (int)(b - tl_trace);
 }
 
+static _Thread_local int tl_incons_steps = 0;   /* steps to the first bound of an inconsistent free set taken so far in this iteration */
 /* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
 static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int test_consistency) {
   double g[3 * OS2R_MAX_DOF + OS2R_MAX_DOF][OS2R_MAX_DOF], w[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
@@ -898,6 +899,7 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
       if (lim < alpha) alpha = lim;
     }
   if (on) { if (isfinite(alpha)) cut = 1; else alpha = 1.0; }
+  if (on && cut) tl_incons_steps += 1;
   if (g_trace > 0) {
     int nviol = 0;
     for (int r = 0; r < nr; ++r) if (fr[r]) { double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi); const double full = rows[r].lambda + mu[r]; nviol += full < lo || full > hi; }
@@ -955,10 +957,14 @@ static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 #define ORC_WARM_ROWS (3 * OS2R_MAX_DOF + OS2R_MAX_DOF)
 #define ORC_WARM_SLOTS (ORC_WARM_ROWS + 1)   /* the last slot: 1.0 once an iteration has left its impulses (the joint rows are remembered) */
 static long long g_dbg_counter[4];   /* diagnostics (orc_debug_counter): [0] warm-started iterations, [1] of those with an active row that has no remembered impulse */
-long long orc_debug_counter(int which, int reset) { long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
+static int g_dbg_on = 0;
+long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
 static int g_lag_box = 0;   /* (orc_set_experimental_lag_box: studies -- 1: the lagged friction box, docs/studies/round4_solver.md) */
 void orc_set_experimental_lag_box(int on) { g_lag_box = on; }
 static int g_warm = 1, g_first = ORC_WARM_FIRST, g_solve_always = 0;
+static double g_stall = 0.0;
+static int g_stall_incons_only = 0;
+void orc_set_experimental_stall(double factor) { g_stall = factor < 0 ? -factor : factor; g_stall_incons_only = factor < 0; }   /* < 0: only rounds with an inconsistent-set step */
 static int g_sweep_after_cut = 0;   /* experiment: a step that a bound cut short is followed by a sweep (which may clamp several rows at once), not by the next solve */
 void orc_set_experimental_sweep_after_cut(int on) { g_sweep_after_cut = on; }
 static int g_max_rounds = 0, g_stop_at_cap = 0;   /* experiment: an environment ends phase 2 after that many (solves, re-test sweep) rounds / when its solves are spent */
@@ -1013,9 +1019,11 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       }
     if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS) {
       int fresh = 0;   /* diagnostics: an active row without a remembered impulse (a new contact, the iteration after a reset) */
-      for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0 && isnan(tl_warm[warm_slot(rows, r)])) fresh = 1;
-      __atomic_fetch_add(&g_dbg_counter[0], 1, __ATOMIC_RELAXED);
-      if (fresh) __atomic_fetch_add(&g_dbg_counter[1], 1, __ATOMIC_RELAXED);
+      if (g_dbg_on) for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0 && isnan(tl_warm[warm_slot(rows, r)])) fresh = 1;
+      if (g_dbg_on) {   /* (shared counters: switched on by the first orc_debug_counter call only -- sixteen threads on one cache line halve the oracle's speed) */
+        __atomic_fetch_add(&g_dbg_counter[0], 1, __ATOMIC_RELAXED);
+        if (fresh) __atomic_fetch_add(&g_dbg_counter[1], 1, __ATOMIC_RELAXED);
+      }
     }
     if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS)
       for (int r = 0; r < nr; ++r) {
@@ -1028,7 +1036,9 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         R->lambda = nl;
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
-    int solves = 0, rounds = 0;
+    int solves = 0, rounds = 0, solves_at_measure = 0, incons_at_measure = 0;
+    if (phase == 1) tl_incons_steps = 0;
+    double e_prev = -1.0;
     if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; tl_last_small = 0; tl_trace_len = 0; }
     if (g_trace < 0) { const char* t = getenv("ORC_TRACE_SOLVES"); g_trace = t ? atoi(t) : 0; }
     for (int it = 0; it < sweeps; ++it) {
@@ -1060,6 +1070,11 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
       if (phase == 1) trace_sweep(moved);
+      /* EXPERIMENT: a round (solves + re-test sweep) that does not bring the measure below g_stall of the last one ends phase 2 */
+      if (phase == 1 && exact > 0 && g_stall > 0.0 && solves > 0 && it + 1 > ORC_EXACT_FIRST(n)) {
+        if (solves > solves_at_measure && e_prev >= 0.0 && moved > g_stall * e_prev && (!g_stall_incons_only || tl_incons_steps > incons_at_measure)) { break; }
+      }
+      if (phase == 1) { e_prev = moved; solves_at_measure = solves; incons_at_measure = tl_incons_steps; }
       if (phase == 1 && exact > 0 && g_max_rounds > 0 && (rounds >= g_max_rounds || (g_stop_at_cap && solves >= exact))) break;   /* experiment: bounded rounds */
       if (phase == 1 && it + 1 < sweeps && moved <= tol) {
         if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) && !(g_solve_always && solves == 0) : (it + 1) % ORC_PGS_GROUP == 0) break;

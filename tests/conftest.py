@@ -10,8 +10,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # Robots that are not compiled in run on the generic kernels in the tests (those are what most of the
 # run-time-model tests are about); the tests of gym_os2r_amd/jit.py switch the specialisation on themselves.
 os.environ.setdefault("OS2R_JIT", "0")
-# code objects built by those tests live in-tree (git-ignored), so the ones built in the CPU container
-# travel to the GPU box with the snapshot instead of being compiled there again
+# code objects built by those tests live in-tree (git-ignored and gpurun-ignored: the GPU box builds its own with its hipcc,
+# ~7 s each; the library itself travels prebuilt)
 KERNEL_CACHE = os.path.join(ROOT, ".kernel_cache")
 
 
