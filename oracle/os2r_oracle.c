@@ -673,6 +673,59 @@ static int block_update_cheap(int n, Row* rows, int r0, double* v, double* moved
   return 1;
 }
 
+/* g_block_kind == 2: the pair update.  The environments that need an exact solve have, as a rule, the normal and ONE tangential
+ * row of one contact free (docs/studies/round4_solver.md): after the Gauss-Seidel pass over the three rows in impulse space,
+ * if the normal row and exactly one tangential row are strictly inside their boxes, that pair is solved exactly (2 x 2); if the
+ * result leaves the box, the row that violates is set on the bound it violates and the other one re-solved alone (taken if it
+ * stays inside); anything else keeps the pass. */
+static int block_update_pair(int n, Row* rows, int r0, double* v, double* moved) {
+  Row* R[3] = {&rows[r0], &rows[r0 + 1], &rows[r0 + 2]};
+  for (int i = 0; i < 3; ++i) if (!(R[i]->d > 0.0)) return 0;
+  double A[3][3], w[3], w0[3], lam[3], l0[3], lo[3], hi[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += R[i]->J[k] * R[j]->T[k]; A[i][j] = s; }
+    double s = -R[i]->target; for (int k = 0; k < n; ++k) s += R[i]->J[k] * v[k];
+    w[i] = s; w0[i] = s; lam[i] = R[i]->lambda; l0[i] = lam[i];
+  }
+  lo[0] = 0.0; hi[0] = INFINITY;
+  for (int i = 1; i < 3; ++i) { hi[i] = R[i]->bound; lo[i] = -hi[i]; }
+  for (int i = 0; i < 3; ++i) {
+    double nl = lam[i] - w[i] / A[i][i];
+    if (nl < lo[i]) nl = lo[i];
+    if (nl > hi[i]) nl = hi[i];
+    const double dl = nl - lam[i];
+    lam[i] = nl;
+    for (int j = 0; j < 3; ++j) w[j] += A[j][i] * dl;
+  }
+  const int fn = lam[0] > lo[0], fx = lam[1] > lo[1] && lam[1] < hi[1], fy = lam[2] > lo[2] && lam[2] < hi[2];
+  if (fn && (fx != fy)) {
+    const int t = fx ? 1 : 2;
+    const double det = A[0][0] * A[t][t] - A[0][t] * A[0][t];
+    if (det > 1e-14 * A[0][0] * A[t][t]) {
+      double dn = -(A[t][t] * w[0] - A[0][t] * w[t]) / det, dt_ = -(A[0][0] * w[t] - A[0][t] * w[0]) / det;
+      double nn = lam[0] + dn, nt = lam[t] + dt_;
+      int ok = nn >= lo[0] && nt >= lo[t] && nt <= hi[t];
+      if (!ok && g_block_kind == 2) {
+        /* one violator: set it on its bound, re-solve the other alone */
+        if (nn < lo[0]) { dn = lo[0] - lam[0]; dt_ = -(w[t] + A[t][0] * dn) / A[t][t]; }
+        else { dt_ = (nt < lo[t] ? lo[t] : hi[t]) - lam[t]; dn = -(w[0] + A[0][t] * dt_) / A[0][0]; }
+        nn = lam[0] + dn; nt = lam[t] + dt_;
+        ok = nn >= lo[0] && nt >= lo[t] && nt <= hi[t];
+      }
+      if (ok) {
+        lam[0] = nn; lam[t] = nt;
+      }
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double dl = lam[i] - l0[i];
+    R[i]->lambda = lam[i];
+    *moved += fabs(w0[i]) * fabs(dl);
+    for (int k = 0; k < n; ++k) v[k] += R[i]->T[k] * dl;
+  }
+  return 1;
+}
+
 /* EXPERIMENT (oracle only, off by default): order of the three rows of a contact inside a phase-2 sweep.
  * 0: normal, x, y (the specification)   1: y, x, normal   2: the less mobile tangential row, the other, normal */
 static int g_row_order = 0;
@@ -704,7 +757,9 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
  * iteration on, a solve that is not cut therefore measures what it leaves on its free rows; if that is more than
  * ORC_EXACT_INCONS of what it found (squared norms), it goes on in the direction of its multipliers -- past the full
  * step -- to the first bound it meets, sets that row on it and solves again, as after a cut. */
-#define ORC_EXACT_INCONS 1e-4
+#define ORC_EXACT_INCONS g_incons
+static double g_incons = 1e-4;   /* (orc_set_experimental_incons: studies) */
+void orc_set_experimental_incons(double v) { g_incons = v; }
 /* EXPERIMENT (oracle only, off by default; docs/studies/round4_solver.md): small free sets solved in the dual.  In the
  * regimes the stepper lives in, an environment that needs a solve has two free rows -- the normal and one tangential row
  * of a sticking-sliding contact, or the normals of two contacts -- seldom three and hardly ever more (joints slide: their
@@ -1056,7 +1111,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         const int r = (phase == 1 && !g_block_solve) ? order[ri] : ri;
         Row* R = &rows[r];
         if (g_block_solve && (g_block_solve == 1 || it < g_block_solve - 1) && phase == 1 && normal_iters > 0 && R->kind == 0 && r + 2 < nr && rows[r + 1].kind == 1 &&
-            rows[r + 2].kind == 1 && (g_block_kind ? block_update_cheap(n, rows, r, v, &moved) : block_update(n, rows, r, v, &moved))) { ri += 2; continue; }
+            rows[r + 2].kind == 1 && (g_block_kind >= 2 ? block_update_pair(n, rows, r, v, &moved) : g_block_kind ? block_update_cheap(n, rows, r, v, &moved) : block_update(n, rows, r, v, &moved))) { ri += 2; continue; }
         if (!(R->d > 0.0)) continue;
         if (phase == 0 && R->kind == 1) continue;
         double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];

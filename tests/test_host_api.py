@@ -478,3 +478,20 @@ def test_code_objects_of_the_built_library_have_no_scratch_and_no_runtime_tables
             out = subprocess.run([os.path.join(kernel_meta.LLVM, "llvm-readelf"), "--symbols", f.name], capture_output=True, text=True).stdout
         tables += [ln.split()[-1] for ln in out.splitlines() if ("Tables" in ln or "CandMeta" in ln) and "OBJECT" in ln]
     assert not tables, sorted(set(tables))[:5]
+
+
+def test_flop_model_prices_the_sweep_units_from_the_source():
+    """tools/flop_model.py: the two sweep units of profiles/flop_model.json are not fitted but counted --
+    a row with nz non-zeros is nz FMA + 1 FMA + 1 ADD + nz FMA, a joint row starts its residual with a MUL -- times 64 lanes;
+    and the committed model prices no solver unit at zero."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import flop_model
+    joint = 64 * sum(4 * (j + 1) + 2 for j in range(5))
+    assert flop_model.sweep_prices("C4", 3) == (joint, 64 * (3 * (15 + 19 + 23)) / 3)
+    assert flop_model.sweep_prices("V1", 3)[0] == 64 * sum(4 * (j + 1) + 2 for j in range(4))
+    model = json.load(open(os.path.join(ROOT, "profiles", "flop_model.json")))
+    for wl in ("C4_f64", "C3_f64", "V1_f64"):
+        k = model[wl]["flops_per_unit"]
+        assert k["sweep"] > 0 and k["body_sweep"] > 0 and k["exact_solve"] > 0, (wl, k)
+    assert model["C4_f64"]["flops_per_unit"]["sweep"] == joint

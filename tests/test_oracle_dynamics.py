@@ -226,3 +226,22 @@ def test_oracle_is_clean_under_the_undefined_behaviour_sanitizer(tmp_path):
     """)
     run = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and "clean" in run.stdout, (run.stdout[-500:], run.stderr[-1500:])
+
+
+def test_default_specification_has_not_drifted(oracle):
+    """tests/golden/spec_trajectories.npz (tools/gen_spec_fixture.py) holds what the oracle's DEFAULT configuration produced when
+    the fixture was written: states, solver state, reward sums and done counts after 200-300 env-steps with device-drawn
+    actions, auto-reset and TimeLimit, four configurations.  Not a reference pin -- a guard: the oracle carries
+    experimental switches and every round edits the solver; a change of what the default does must be a decision (regenerate
+    the file and say why), not an accident.  Bounds: the trajectories are chaotic once the robots flail, so the same binary is
+    asked to reproduce itself to 1e-9 (compiler / libm differences between the build container and the GPU box stay far below)."""
+    import tools.gen_spec_fixture as gen
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spec_trajectories.npz"))
+    for case in gen.CASES:
+        got = gen.run(case)
+        for k, v in got.items():
+            r = ref[k]
+            if v.dtype.kind in "ui":
+                assert np.array_equal(v, r), k
+            else:
+                np.testing.assert_allclose(v, r, rtol=1e-9, atol=1e-9, err_msg=k)
