@@ -826,6 +826,8 @@ static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu
   tl_trace_len = (int)(b - tl_trace);
 }
 
+static int g_incons_once = 0;
+void orc_set_experimental_incons_once(int n) { g_incons_once = n; }
 static _Thread_local int tl_incons_steps = 0;   /* steps to the first bound of an inconsistent free set taken so far in this iteration */
 /* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
 static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int test_consistency) {
@@ -943,7 +945,9 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     if (full < lo || full > hi) cut = 1;
   }
   /* if so, the largest feasible fraction of the step; an inconsistent free set: the step to the first bound, however long */
-  const int on = test_consistency && !cut && left > ORC_EXACT_INCONS * found;
+  /* EXPERIMENT g_incons_once: an environment takes at most that many inconsistent-set steps per physics iteration (the period-2
+   * cycling of docs/studies/round4_solver.md is a second, third, ... such step undoing the first) */
+  const int on = test_consistency && !cut && left > ORC_EXACT_INCONS * found && (g_incons_once <= 0 || tl_incons_steps < g_incons_once);
   double alpha = on ? INFINITY : 1.0;
   if (cut || on)
     for (int r = 0; r < nr; ++r) {
