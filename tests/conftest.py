@@ -13,6 +13,10 @@ os.environ.setdefault("OS2R_JIT", "0")
 # code objects built by those tests live in-tree (git-ignored and gpurun-ignored: the GPU box builds its own with its hipcc,
 # ~7 s each; the library itself travels prebuilt)
 KERNEL_CACHE = os.path.join(ROOT, ".kernel_cache")
+# shards on streams (HipVecEnv(num_splits=...), bench.py --splits) want a hardware queue per shard stream; the HIP runtime reads
+# this when it initialises -- in the test process that is long before the shard tests run (the suite ran them
+# on shared queues, with the warning)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def pytest_configure(config):
