@@ -748,7 +748,9 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
 #define ORC_EXACT_FIRST_COLD(n) ((n) >= 5 ? 6 : 4)   /* (studies only: sweeps before the first check of a cold start, as in round 3) */
 #define ORC_EXACT_FIRST(n) (cold_now ? ORC_EXACT_FIRST_COLD(n) : g_first)   /* sweeps before the first check */
 #define ORC_EXACT_EPS 1e-6
-#define ORC_EXACT_PROX 3
+#define ORC_EXACT_PROX g_prox
+static int g_prox = 3;   /* (orc_set_experimental_prox: studies) */
+void orc_set_experimental_prox(int k) { g_prox = k; }
 #define ORC_EXACT_SNAP 1e-12
 /* A free set can be INCONSISTENT: more sticking rows than the degrees of freedom they act on (four or five of them on
  * the three dof of `monopod-fixed`, two sticking contacts in five dof).  The solve then ends at the least-squares point

@@ -57,6 +57,7 @@ long long orc_debug_counter(int which, int reset);   /* diagnostics, see os2r_or
 void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged friction box (no phase 1 for an environment that remembers every active row) */
 void orc_set_experimental_incons(double threshold);   /* studies: the inconsistent-free-set test's threshold (1e-4) */
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
+void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (3) */
 void orc_set_experimental_stall(double factor);
 void orc_set_experimental_sweep_after_cut(int on);
 void orc_set_experimental_clamp_all(int on);
