@@ -3,6 +3,7 @@ they are checked against (1) the known answers of SURVEY.md Appendix A, derived 
 numbers by a COM-Jacobian route, (2) an independent finite-difference Lagrangian
 (tests/lagrange_ref.py) and (3) invariants."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -245,3 +246,14 @@ def test_default_specification_has_not_drifted(oracle):
                 assert np.array_equal(v, r), k
             else:
                 np.testing.assert_allclose(v, r, rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+def test_world_frame_formulation_of_the_articulated_body_passes(oracle):
+    """tests/diag/world_aba.py restates the articulated-body passes in world coordinates about one fixed point, with the
+    unit-torque columns of the factor of Minv fused into the inward pass (costed as a kernel formulation, and
+    dropped on its instruction count).  A third, independent route to the same numbers: it must agree with the oracle's dense
+    spatial algebra on accelerations and on Minv = Lc Lc^T at random states with mass scaling and implicit damping."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
+    import world_aba
+    for name, (e_qdd, e_minv) in world_aba.compare(n_states=12, seed=3).items():
+        assert e_qdd < 1e-10 and e_minv < 1e-10, (name, e_qdd, e_minv)
