@@ -166,7 +166,8 @@ def counted_flops(sims, cks, steps, dr, workload, skip=0):
     for sim, ck in zip(sims, cks):
         try:
             sim.set_state(ck["q"], ck["qd"])
-            sim.set_solver_state(ck["solver_lambda"], ck["solver_flags"])
+            if "solver_lambda" in ck:
+                sim.set_solver_state(ck["solver_lambda"], ck["solver_flags"])
             sim.set_action_history(0, ck["hist0"]); sim.set_action_history(1, ck["hist1"])
             if dr:                                    # (restoring parameters would switch a nominal handle to per-env ones)
                 for f, v in ck["params"].items():

@@ -20,7 +20,7 @@ SYMBOLS = ["os2r_abi_version", "os2r_create", "os2r_destroy", "os2r_reset", "os2
            "os2r_rollout", "os2r_get_state", "os2r_set_state", "os2r_get_solver_state", "os2r_set_solver_state", "os2r_get_action_history", "os2r_set_action_history",
            "os2r_set_params", "os2r_get_params", "os2r_get_episode_info", "os2r_set_episode_info", "os2r_get_action_violations",
            "os2r_get_step_count",
-           "os2r_set_step_count", "os2r_bench_steps", "os2r_bench_steps_multi", "os2r_set_work_counters", "os2r_set_done_reasons", "os2r_model_is_compiled_in",
+           "os2r_set_step_count", "os2r_bench_steps", "os2r_bench_steps_multi", "os2r_set_work_counters", "os2r_set_done_reasons", "os2r_set_done_mask", "os2r_get_violation_mirror", "os2r_model_is_compiled_in",
            "os2r_register_model_kernels", "os2r_last_error"]
 
 
@@ -61,6 +61,8 @@ def load():
     lib.os2r_bench_steps_multi.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]
     lib.os2r_set_work_counters.argtypes = [vp, vp]
     lib.os2r_set_done_reasons.argtypes = [vp, vp]
+    lib.os2r_set_done_mask.argtypes = [vp, u8p]
+    lib.os2r_get_violation_mirror.argtypes = [vp, C.POINTER(vp)]
     lib.os2r_model_is_compiled_in.argtypes = [C.POINTER(abi.Os2rModel)]
     lib.os2r_register_model_kernels.argtypes = [C.POINTER(abi.Os2rModel), C.c_int32, C.c_int32, C.c_char_p]
     lib.os2r_last_error.argtypes = [vp]

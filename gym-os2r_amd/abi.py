@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Mapping, Optional
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_DOF = 5
 MAX_CAND = 192
 MAX_OBS = 12

@@ -108,6 +108,9 @@ struct SimBase {
   uint8_t* b_done = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint16_t* reason = nullptr;           // caller-owned done-reason buffer (os2r_set_done_reasons)
+  uint8_t* done_mask = nullptr;         // caller-owned done-mask buffer (os2r_set_done_mask)
+  uint32_t* mirror_host = nullptr;      // two words of mapped, coherent host memory (os2r_get_violation_mirror) ...
+  uint32_t* mirror_dev = nullptr;       // ... and the address the kernels write them through
   unsigned long long* debug = nullptr;  // diagnostic stamp builds only
 };
 
@@ -265,6 +268,8 @@ StepArgs<T> make_args(Os2rSim* s) {
   a.solver_l = (T*)s->solver_l; a.solver_flags = s->solver_flags;
   a.debug = s->debug;
   a.reason = s->reason;
+  a.done_mask = s->done_mask;
+  a.mirror = s->mirror_dev;
   task_layout(s->cfg.task, a.layout_kinds, a.layout_srcs, a.layout_dim);
   return a;
 }
@@ -316,6 +321,7 @@ int do_rollout(Os2rSim* s, int K, const void* actions, void* obs, void* reward, 
     StepArgs<T> a = make_args<T>(s);
     a.actions = (const T*)actions; a.obs = (T*)obs; a.reward = (T*)reward; a.done = done; a.term_obs = (T*)term;
     a.reason = reason;
+    a.done_mask = nullptr;   // (a rollout writes neither of the per-step buffers set on the handle)
     a.rollout_steps = K;
     const int rc = Launcher<T>::step(s->nq, s->model_id, s->cfg.contact != 0, s->dr, a, st);
     if (rc == 0) {
@@ -325,6 +331,8 @@ int do_rollout(Os2rSim* s, int K, const void* actions, void* obs, void* reward, 
     }
   }
   uint16_t* const reason_keep = s->reason;
+  uint8_t* const mask_keep = s->done_mask;
+  s->done_mask = nullptr;
   int rc = OS2R_OK;
   for (int k = 0; k < K && rc == OS2R_OK; ++k) {
     s->reason = reason ? reason + (size_t)k * N : nullptr;
@@ -333,6 +341,7 @@ int do_rollout(Os2rSim* s, int K, const void* actions, void* obs, void* reward, 
                     term ? (T*)term + (size_t)k * N * D : nullptr, st);
   }
   s->reason = reason_keep;
+  s->done_mask = mask_keep;
   return rc;
 }
 
@@ -368,6 +377,8 @@ void free_all(Os2rSim* s) {
   s->allocs.clear();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->mirror_host) (void)hipHostFree(s->mirror_host);
+  s->mirror_host = s->mirror_dev = nullptr;
 }
 
 int param_view(Os2rSim* s, int field, void** base, int* count) {
@@ -457,6 +468,15 @@ int os2r_create(const Os2rConfig* cfg, Os2rSim** out) {
         hipMemcpy(s->task_d, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess) { s->err = "model upload failed"; return fail(OS2R_ERR_HIP); }
   }
   if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { s->err = "hipEventCreate failed"; return fail(OS2R_ERR_HIP); }
+  // the violation mirror: pinned host memory that the device writes with plain system-scope stores (no atomics across PCIe)
+  {
+    void* hp = nullptr; void* dp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { s->err = "hipHostMalloc (violation mirror) failed"; return fail(OS2R_ERR_ALLOC); }
+    s->mirror_host = (uint32_t*)hp;
+    std::memset(hp, 0, 64);
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { s->err = "hipHostGetDevicePointer (violation mirror) failed"; return fail(OS2R_ERR_HIP); }
+    s->mirror_dev = (uint32_t*)dp;
+  }
   rc = cfg->dtype == OS2R_F64 ? init_params<double>(s, nullptr) : init_params<float>(s, nullptr);
   if (rc) return fail(rc);
   rc = cfg->dtype == OS2R_F64 ? do_reset<double>(s, nullptr, nullptr, nullptr) : do_reset<float>(s, nullptr, nullptr, nullptr);
@@ -638,6 +658,12 @@ int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void*
   return OS2R_OK;
 }
 
+int os2r_get_violation_mirror(Os2rSim* sim, const volatile uint32_t** host_words) {
+  if (!sim || !host_words) return OS2R_ERR_INVALID;
+  *host_words = sim->mirror_host;
+  return OS2R_OK;
+}
+
 int os2r_get_step_count(Os2rSim* sim, uint64_t* out) {
   if (!sim || !out) return OS2R_ERR_INVALID;
   *out = sim->step_count;
@@ -688,6 +714,12 @@ int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev) {
 int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev) {
   if (!sim) return OS2R_ERR_INVALID;
   sim->reason = reason_dev;
+  return OS2R_OK;
+}
+
+int os2r_set_done_mask(Os2rSim* sim, uint8_t* mask_dev) {
+  if (!sim) return OS2R_ERR_INVALID;
+  sim->done_mask = mask_dev;
   return OS2R_OK;
 }
 

@@ -47,11 +47,7 @@ template <> struct StdSolver<float> { static constexpr int kNormalIters = 3; sta
 // the velocity following row by row; a row without a remembered impulse (a body that had no contact then; every row
 // after a reset) keeps what phase 1 gave it.  The solution moves by a thousandth per iteration, so warm_first(nq) sweeps
 // identify the active set before the first check (same-box A/B of 2 / 3 / 4 sweeps in round 3).
-#ifdef OS2R_WARM_FIRST   // (timing experiments only)
-__host__ __device__ constexpr int warm_first(int) { return OS2R_WARM_FIRST; }
-#else
 __host__ __device__ constexpr int warm_first(int) { return 3; }
-#endif
 // The default cap on the sweeps of phase 2 (first sweeps and re-test sweeps together): sweep_cap_base(nq) + kExactRounds
 // (the numbers of round 3, whose cold first iteration ran sweep_cap_base(nq) sweeps before its first check)
 __host__ __device__ constexpr int sweep_cap_base(int nq) { return nq >= 5 ? 6 : 4; }
@@ -200,6 +196,8 @@ struct StepArgs {
   unsigned long long* __restrict__ debug;  // diagnostic stamp builds only (else null)
   unsigned long long* __restrict__ counters;  // work counters of the counting kernel variants (os2r_set_work_counters), else null
   uint16_t* __restrict__ reason;              // [N] which observation slots left the reset space in this step (os2r_set_done_reasons), else null
+  uint8_t* __restrict__ done_mask;            // [N] 1 where `done` is non-zero, else 0 (os2r_set_done_mask: the bool a gym-level step returns), else null
+  uint32_t* __restrict__ mirror;              // two words of mapped host memory (os2r_get_violation_mirror), written by the first wave of every step launch
   // host side of the launch only: the observation layout of the handle's task, 4 bits per slot (slot 0 lowest),
   // compared with the layouts that exist as compile-time variants of the step kernel
   unsigned long long layout_kinds, layout_srcs;
@@ -1283,48 +1281,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   };
   // live_only: the sweep runs under the mask of a few lanes (the exact finish's loop): a body that none of them touches
   // has reciprocals 0 in all of them -- its rows would reproduce themselves -- and is skipped
-#ifdef OS2R_PAIR_FIX
-  // EXPERIMENT (timing only: the oracle does not have it): after the three scalar rows of a contact, if the normal and exactly
-  // one tangential row are strictly inside their boxes, that pair is solved exactly (2 x 2); a violator goes on its bound and
-  // the other row is re-solved alone
-  auto pair_fix = [&](int b) {
-    const T lim = limfix[b];
-    const bool fn = (ln[b] > T(0)) & (dn[b] > T(0));
-    const bool fx = (lx[b] > -lim) & (lx[b] < lim), fy = (ly[b] > -lim) & (ly[b] < lim);
-    const bool pair = fn & (fx != fy);
-    if (__ballot(pair) == 0ull) return;
-    T rn = -erv[b], rx = T(0), ry = T(0), anx = T(0), any_ = T(0);
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-      if (k <= b) {
-        rn = fma_t(Gr[b][0][k], y[k], rn); rx = fma_t(Gr[b][1][k], y[k], rx); ry = fma_t(Gr[b][2][k], y[k], ry);
-        anx = fma_t(Gr[b][0][k], Gr[b][1][k], anx); any_ = fma_t(Gr[b][0][k], Gr[b][2][k], any_);
-      }
-    const T rt = fx ? rx : ry, ant = fx ? anx : any_, dt_ = fx ? dx[b] : dy[b], lt = fx ? lx[b] : ly[b];
-    const T k2 = ant * dn[b] * dt_;
-    const T om = fma_t(-k2, ant, T(1));
-    const bool reg = om > T(1e-14);
-    const T s = rcp_t(reg ? om : T(1));
-    T dln = fma_t(k2, rt, -rn * dn[b]) * s, dlt = fma_t(k2, rn, -rt * dt_) * s;
-    const T nn = ln[b] + dln, nt = lt + dlt;
-    const bool ok = (nn >= T(0)) & (nt >= -lim) & (nt <= lim);
-    const bool nviol = nn < T(0);
-    const T bnd = nt < -lim ? -lim : lim;
-    const T dln2 = nviol ? -ln[b] : -fma_t(ant, bnd - lt, rn) * dn[b];
-    const T dlt2 = nviol ? -fma_t(ant, -ln[b], rt) * dt_ : bnd - lt;
-    const T nn2 = ln[b] + dln2, nt2 = lt + dlt2;
-    const bool ok2 = (nn2 >= T(0)) & (nt2 >= -lim) & (nt2 <= lim);
-    dln = ok ? dln : dln2; dlt = ok ? dlt : dlt2;
-    const bool take = pair & reg & (ok | ok2);
-    dln = take ? dln : T(0); dlt = take ? dlt : T(0);
-    const T dlx = fx ? dlt : T(0), dly = fx ? T(0) : dlt;
-    ln[b] += dln; lx[b] += dlx; ly[b] += dly;
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-      if (k <= b) y[k] = fma_t(Gr[b][0][k], dln, fma_t(Gr[b][1][k], dlx, fma_t(Gr[b][2][k], dly, y[k])));
-  };
-#endif
-  auto sweep = [&](auto coupled, auto first, auto measure_, bool live_only = false, bool pair = false) {
+  auto sweep = [&](auto coupled, auto first, auto measure_, bool live_only = false) {
     constexpr bool measure = decltype(measure_)::value;
     constexpr int kFirst = decltype(first)::value;
 #pragma unroll
@@ -1337,9 +1294,6 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       const T lim = limfix[b];
       contact_row(b, 1, T(0), dx[b], lx[b], -lim, lim, true, measure);
       contact_row(b, 2, T(0), dy[b], ly[b], -lim, lim, true, measure);
-#ifdef OS2R_PAIR_FIX
-      if (pair) pair_fix(b);
-#endif
     }
     joint_rows(measure);
   };
@@ -1638,12 +1592,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     int kExactFirst = warm_first(NQ);
     asm volatile("" : "+s"(kExactFirst));
     const int nfirst = pgs_iters < kExactFirst ? pgs_iters : kExactFirst;
-#ifdef OS2R_PAIR_FIX
-    if (nfirst >= 2) sweep(std::false_type{}, first, std::false_type{}, false, true);
-    for (int k = 1; k + 1 < nfirst; ++k) sweep(std::false_type{}, first, std::false_type{});
-#else
     for (int k = 0; k + 1 < nfirst; ++k) sweep(std::false_type{}, first, std::false_type{});
-#endif
     if (nfirst > 0) { moved = T(0); sweep(std::false_type{}, first, std::true_type{}); }
     int sweeps = nfirst, solves = 0;
     bool live = nfirst > 0 && moved > tol_v && sweeps < pgs_iters;

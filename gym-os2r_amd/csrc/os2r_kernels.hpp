@@ -446,6 +446,14 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
   }
   const TaskPtr<T> ts_launch = as_const(A.task);
   const int D = LAY::kStatic ? LAY::kDim : ts_launch->obs_dim;
+  // The host's view of the clamped-action count (os2r_get_violation_mirror): the first wave of a launch copies the count that
+  // every EARLIER launch left -- they have all finished: stream order -- and this launch's step counter into two words of mapped
+  // host memory, so a host binding can look at it without a copy, an event or a wait on the step path.
+  if (blockIdx.x == 0 && lane == 0 && A.mirror) {
+    const unsigned seen = __hip_atomic_load(A.violations, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(A.mirror, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(A.mirror + 1, (uint32_t)A.step_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 #ifdef OS2R_STAMPS
   unsigned long long stamps[kStamps] = {}, stamp_prev = __builtin_amdgcn_s_memtime();
   stamps[10] = stamp_prev - stamp_entry;   // prologue: loads, action, torques
@@ -609,6 +617,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
       if (Ae.reward) Ae.reward[ko + ep] = rew;
       if (Ae.done) Ae.done[ko + ep] = flag;
       if (Ae.reason) Ae.reason[ko + ep] = (uint16_t)why;
+      if (Ae.done_mask) Ae.done_mask[ko + ep] = flag != 0 ? (uint8_t)1 : (uint8_t)0;
     }
     if (valid) {
 #pragma unroll

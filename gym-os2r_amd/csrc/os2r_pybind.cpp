@@ -68,6 +68,8 @@ PYBIND11_MODULE(_os2r_py, m) {
   });
   m.def("set_work_counters", [](addr h, addr buf) { return os2r_set_work_counters(H(h), (uint64_t*)P(buf)); });
   m.def("set_done_reasons", [](addr h, addr buf) { return os2r_set_done_reasons(H(h), (uint16_t*)P(buf)); });
+  m.def("set_done_mask", [](addr h, addr buf) { return os2r_set_done_mask(H(h), (uint8_t*)P(buf)); });
+  m.def("get_violation_mirror", [](addr h) { const volatile uint32_t* w = nullptr; int rc = os2r_get_violation_mirror(H(h), &w); return py::make_tuple(rc, (addr)w); });
   m.def("model_is_compiled_in", [](addr model) { return os2r_model_is_compiled_in((const Os2rModel*)P(model)); });
   m.def("register_model_kernels", [](addr model, int dtype, int device, const std::string& path) {
     return os2r_register_model_kernels((const Os2rModel*)P(model), dtype, device, path.c_str()); });

@@ -122,8 +122,9 @@ class HipRuntime:
         self._randomize_params = False
         self._gravity_rollouts = 0
         self._sim = None
-        self._bad_flag, self._bad_event, self._bad_pending, self._bad_slot = None, None, [False, False], 0
+        self._bad_pending = []    # step counters of the launches with device actions whose verdict is still out (oldest first)
         self._bad_seen = 0        # running count of clamped actions already reported
+        self._bad_flag = None     # pinned word for the rare direct read (reset / close)
         cfg = getattr(self.task, "cfg", None) or SettingsConfig()
         self.model = dict(get_model(cfg.get_config(f"task_modes/{self.task.task_mode}/model")))
         self.pose_names = list(cfg.get_config("/resets").keys())
@@ -167,7 +168,7 @@ class HipRuntime:
             self._sim = HipSim(cfg, device=o["device"])
             if o["done_reasons"]:
                 self._sim.done_reasons(True)
-            self._bad_seen, self._bad_pending = 0, [False, False]     # a new handle counts from zero
+            self._bad_seen, self._bad_pending = 0, []     # a new handle counts from zero
         return self._sim
 
     def reset(self, mask=None):
@@ -192,7 +193,9 @@ class HipRuntime:
         # The action space is enforced (gazebo_runtime.py:67-68 warns; the task asserts).  Host actions
         # are checked on the host before the upload.  Device actions are checked by the kernel and the
         # verdict is read two calls later (or in reset()/close()): reading it earlier would make the
-        # host wait for a kernel that is still running, every step.
+        # host wait for a kernel that is still running, every step.  Reading it costs a load from pinned
+        # host memory that the next launch's first wave writes (include/os2r.h: os2r_get_violation_mirror):
+        # no copy, no event and no other kernel between two env-step launches.
         self._raise_if_bad_actions()
         if not isinstance(actions, torch.Tensor) or not actions.is_cuda:
             a_host = np.asarray(actions, dtype=np.float64)
@@ -202,19 +205,11 @@ class HipRuntime:
         if a.dim() == 1 and self.num_envs == 1:
             a = a.reshape(1, 2)
         device_actions = isinstance(actions, torch.Tensor) and actions.is_cuda
-        obs, rew, flags, term = sim.step(a, want_terminal=True)
         if device_actions:
-            # the kernel clamps out-of-range actions and counts them; the running count (never cleared: one
-            # small copy per step instead of a copy and a memset) travels to pinned host memory behind this
-            # step and is compared with the count already reported two calls later
-            if self._bad_flag is None:
-                self._bad_flag = torch.zeros(2, dtype=torch.int32).pin_memory()
-                self._bad_event = [torch.cuda.Event(), torch.cuda.Event()]
-            k = self._bad_slot
-            sim.action_violations_into(self._bad_flag[k:k + 1], clear=False)
-            self._bad_event[k].record(torch.cuda.current_stream(sim.device))
-            self._bad_pending[k] = True
-            self._bad_slot = 1 - k
+            # the kernel clamps out-of-range actions and counts them; the launch AFTER this one mirrors the running count
+            # (never cleared) to the host, and it is compared with the count already reported two calls later
+            self._bad_pending.append(sim.step_count & 0xFFFFFFFF)
+        obs, rew, flags, term, done = sim.step(a, want_terminal=True, want_mask=True)   # `done` = flags != 0, from the same launch
         if getattr(self.task, "host_reward", False):
             # custom reward class (no in-kernel formula): the reference's extension point is kept
             # through a host evaluation on the stepped (pre-reset) observation and the action
@@ -232,24 +227,46 @@ class HipRuntime:
             why = sim.reasons.clone()
             lazy["done_reason"] = lambda: why                      # bit d: observation d left the reset space
         info = BatchedInfo(done_flags=flags, terminal_observation=term, lazy=lazy)
-        return obs, rew, flags != 0, info
+        return obs, rew, done, info
 
     def _raise_if_bad_actions(self, drain: bool = False):
-        """Look at the verdicts that are due: the one of two calls ago (its kernel has finished while the
-        last one runs, so nothing waits), or all of them when draining in reset()/close()."""
-        for k in ((self._bad_slot, 1 - self._bad_slot) if drain else (self._bad_slot,)):   # oldest first
-            if self._bad_pending[k]:
-                self._bad_event[k].synchronize()
-                self._bad_pending[k] = False
-                if int(self._bad_flag[k]) != self._bad_seen:
-                    # one report per burst: the verdict of the step behind this one is taken in as well
-                    o = 1 - k
-                    if self._bad_pending[o]:
-                        self._bad_event[o].synchronize()
-                        self._bad_pending[o] = False
-                    self._bad_seen = max(int(self._bad_flag[k]), int(self._bad_flag[o]))
-                    raise AssertionError("invalid: actions of an earlier step() left the action space [-1, 1] "
-                                         "(they were clamped, as the backend clamps the torque)")
+        """Look at the verdicts that are due.  The verdict on the launch with step counter k is in the mirror once a later
+        launch has started (mirror[1] > k).  A step waits until at most ONE of its earlier launches is unconfirmed -- the one
+        of two calls ago has then been checked, and the host runs at most two launches ahead of the device, as with the event
+        of rounds 1-4, without an event; reset() / close() (drain) wait for the stream and read the count directly."""
+        if self._sim is None or not self._bad_pending:
+            return
+        import time
+        sim = self._sim
+        count = None
+        if drain:
+            import torch
+            if self._bad_flag is None:
+                self._bad_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            sim.action_violations_into(self._bad_flag, clear=False)
+            torch.cuda.current_stream(sim.device).synchronize()
+            count = int(self._bad_flag[0])
+            self._bad_pending.clear()
+        else:
+            m = sim.violation_mirror()
+            deadline = None
+            while self._bad_pending:
+                started = int(m[1])
+                if ((started - self._bad_pending[0] - 1) & 0xFFFFFFFF) < 0x80000000:    # a launch behind the oldest one has started
+                    count = int(m[0])
+                    self._bad_pending.pop(0)
+                    continue
+                if len(self._bad_pending) < 2:
+                    break
+                if deadline is None:
+                    deadline = time.perf_counter() + 5.0
+                elif time.perf_counter() > deadline:     # (launches on a stream that is not running: do not hang on them)
+                    return self._raise_if_bad_actions(drain=True)
+                time.sleep(0)
+        if count is not None and count != self._bad_seen:
+            self._bad_seen = count      # one report per burst
+            raise AssertionError("invalid: actions of an earlier step() left the action space [-1, 1] "
+                                 "(they were clamped, as the backend clamps the torque)")
 
     def done_reason_names(self, mask: int):
         """The observation names behind a `done_reason` bitmask (what tasks/monopod.py:288-296 logs in the reference)."""

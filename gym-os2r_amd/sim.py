@@ -106,6 +106,14 @@ class _PybindLib:
     def os2r_set_done_reasons(self, h, buf):
         return self.m.set_done_reasons(self._a(h), self._a(buf))
 
+    def os2r_set_done_mask(self, h, buf):
+        return self.m.set_done_mask(self._a(h), self._a(buf))
+
+    def os2r_get_violation_mirror(self, h, out_ref):
+        rc, v = self.m.get_violation_mirror(self._a(h))
+        out_ref._obj.value = v
+        return rc
+
     def os2r_last_error(self, h):
         return self.m.last_error(self._a(h)).encode()
 
@@ -135,6 +143,7 @@ class HipSim:
         from . import jit
         self.specialised = jit.specialise(_lib.load(), cfg)
         self._counters = None                         # count_work(True) allocates the work counters
+        self._mirror = None                           # violation_mirror(): numpy view of the handle's two host words
         self.reasons = None                           # done_reasons(True) allocates the done-reason output
         self._h = C.c_void_p()
         rc = self._lib.os2r_create(C.byref(cfg), C.byref(self._h))
@@ -174,15 +183,33 @@ class HipSim:
             pass
 
     # -- hot path ---------------------------------------------------------------------------
-    def step(self, actions: Optional[torch.Tensor] = None, want_terminal: bool = True):
-        """-> obs [N,D], reward [N], done [N] uint8 flags, terminal_obs [N,D] or None."""
+    def step(self, actions: Optional[torch.Tensor] = None, want_terminal: bool = True, want_mask: bool = False):
+        """-> obs [N,D], reward [N], done [N] uint8 flags, terminal_obs [N,D] or None (and, want_mask: done_mask [N] bool --
+        `flags != 0`, written by the same launch: include/os2r.h, os2r_set_done_mask)."""
         a = None if actions is None else self._in(actions, (self.N, 2))
         obs, rew = self._new(self.N, self.D), self._new(self.N)
         done = self._new(self.N, dtype=torch.uint8)
         term = self._new(self.N, self.D) if want_terminal else None
+        if want_mask:
+            mask = self._new(self.N, dtype=torch.bool)     # one byte per element; the kernel stores 0 / 1
+            self._check(self._lib.os2r_set_done_mask(self._h, _ptr(mask)), "os2r_set_done_mask")
         self._check(self._lib.os2r_step(self._h, _ptr(a), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term),
                                         self._stream()), "os2r_step")
+        if want_mask:
+            self._check(self._lib.os2r_set_done_mask(self._h, None), "os2r_set_done_mask")   # the handle keeps no pointer to a tensor it does not own
+            return obs, rew, done, term, mask
         return obs, rew, done, term
+
+    def violation_mirror(self):
+        """numpy uint32 [2] view of the handle's two words of pinned host memory (include/os2r.h: os2r_get_violation_mirror):
+        [0] the running count of clamped caller actions as the launches before the newest one that has STARTED left it,
+        [1] the low 32 bits of that launch's step counter.  Reading it costs a load: no copy, no event, no wait."""
+        if self._mirror is None:
+            import numpy as np
+            p = C.c_void_p()
+            self._check(self._lib.os2r_get_violation_mirror(self._h, C.byref(p)), "os2r_get_violation_mirror")
+            self._mirror = np.ctypeslib.as_array((C.c_uint32 * 2).from_address(p.value))
+        return self._mirror
 
     def step_into(self, actions, obs, rew, done, term=None):
         """Allocation-free variant writing into caller tensors."""
@@ -203,8 +230,26 @@ class HipSim:
                                            self._stream()), "os2r_rollout")
         return obs, rew, done, term, why
 
+    def _out(self, t, shape, dtype, what):
+        """A caller-owned output (or raw input) tensor handed to the library by address: it must be what the kernel assumes."""
+        if t is None:
+            return
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+            raise ValueError(f"{what}: expected a contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}, got "
+                             f"{getattr(t, 'dtype', type(t))} {tuple(getattr(t, 'shape', ()))} on {getattr(t, 'device', None)}")
+
     def rollout_into(self, nsteps: int, actions, obs, rew, done, term=None, reasons=None):
-        """Allocation-free variant of rollout() writing into caller tensors ([K,N,...])."""
+        """Allocation-free variant of rollout() writing into caller tensors ([K,N,...]); shapes, dtypes, device and
+        contiguity are checked (the library takes addresses: a wrong K or dtype would write out of bounds)."""
+        K = int(nsteps)
+        if obs is None or rew is None or done is None:
+            raise ValueError("rollout_into: obs, rew and done are required")
+        self._out(actions, (K, self.N, 2), self.dtype, "actions")
+        self._out(obs, (K, self.N, self.D), self.dtype, "obs")
+        self._out(rew, (K, self.N), self.dtype, "rew")
+        self._out(done, (K, self.N), torch.uint8, "done")
+        self._out(term, (K, self.N, self.D), self.dtype, "term")
+        self._out(reasons, (K, self.N), torch.int16, "reasons")
         self._check(self._lib.os2r_rollout(self._h, int(nsteps), _ptr(actions), _ptr(obs), _ptr(rew), _ptr(done), _ptr(term),
                                            _ptr(reasons), self._stream()), "os2r_rollout")
 
@@ -276,6 +321,9 @@ class HipSim:
         return q, qd
 
     def set_state(self, q=None, qd=None):
+        """Set q and / or qd ([nq, N]).  Either way the contact solver's state is cleared (include/os2r.h: a state set from
+        outside starts like a reset, also when only one of the two is given): a caller that nudges qd every step gives up the
+        warm start of the contact solve -- restore it with set_solver_state() afterwards if the old impulses still apply."""
         q = None if q is None else self._in(q, (self.nq, self.N))
         qd = None if qd is None else self._in(qd, (self.nq, self.N))
         self._check(self._lib.os2r_set_state(self._h, _ptr(q), _ptr(qd), self._stream()), "os2r_set_state")
@@ -348,7 +396,8 @@ class HipSim:
     def restore(self, ck: dict):
         """Continue from a `checkpoint()` (of this or of another handle with the same configuration)."""
         self.set_state(ck["q"], ck["qd"])
-        self.set_solver_state(ck["solver_lambda"], ck["solver_flags"])   # (after set_state, which clears it)
+        if "solver_lambda" in ck and "solver_flags" in ck:     # (after set_state, which clears it; a checkpoint written before
+            self.set_solver_state(ck["solver_lambda"], ck["solver_flags"])   # ABI 4 has none: the solver starts cold, as after a reset)
         self.set_action_history(0, ck["hist0"]); self.set_action_history(1, ck["hist1"])
         for f, v in ck["params"].items():
             self.set_params(f, v)

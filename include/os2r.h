@@ -39,7 +39,7 @@ extern "C" {
 #define OS2R_API
 #endif
 
-#define OS2R_ABI_VERSION 4
+#define OS2R_ABI_VERSION 5
 
 #define OS2R_MAX_DOF 5      /* yaw, pitch, boom_connector, hip, knee                       */
 #define OS2R_MAX_CAND 192   /* ground-contact candidate points of one model                */
@@ -264,6 +264,13 @@ OS2R_API int os2r_register_model_kernels(const Os2rModel* model, int32_t dtype, 
  * of offending environments to dst (device or pinned host memory, ordered on the stream, so a
  * host binding can look at it one call later without stalling) and clears it if `clear`.   */
 OS2R_API int os2r_get_action_violations(Os2rSim* sim, uint32_t* dst, int32_t clear, void* stream);
+/* The same count without a copy on the step path (ABI 5): *host_words points at two 32-bit words of pinned host memory owned by
+ * the handle.  The first wave of every os2r_step / os2r_rollout launch stores there [0] the running count as EARLIER launches left
+ * it (what os2r_get_action_violations would copy before this launch; never cleared by this path) and [1] the low 32 bits of the
+ * launch's step counter (os2r_get_step_count before the call), so a host binding reads the verdict on step k once [1] > k --
+ * a plain load, no event, no memcpy between the launches (a 4-byte copy plus an event per step cost a 65 536-env gym-level
+ * loop 8 % of its rate: profiles/r05_host_surface.txt).  Valid until os2r_destroy.                                          */
+OS2R_API int os2r_get_violation_mirror(Os2rSim* sim, const volatile uint32_t** host_words);
 
 /* State access in chain dof order, SoA [nq][num_envs], handle's dtype.  os2r_set_state also clears the contact
  * solver's state (below): a state set from outside starts like a reset.                                     */
@@ -335,6 +342,13 @@ OS2R_API int os2r_set_work_counters(Os2rSim* sim, uint64_t* counters_dev);
  * slot d of the task's observation layout (a non-finite value counts) -- i.e. what set bit0 of `done`; 0 for an
  * environment that is not done or only truncated.  NULL switches it off.                                       */
 OS2R_API int os2r_set_done_reasons(Os2rSim* sim, uint16_t* reason_dev);
+
+/* Done mask (ABI 5): while a buffer of num_envs uint8 (device memory) is set, every os2r_step also writes 1 where `done` is
+ * non-zero and 0 elsewhere -- the boolean `done` that GazeboRuntime.step returns (gym_os2r/runtimes/gazebo_runtime.py:91-97)
+ * and SubprocVecEnv stacks (common/vec_env/subproc_vec_env.py:119-123), so a host binding needs no kernel of its own to turn
+ * the flag bits into it.  A binding that hands out a fresh array per step sets the pointer before each call (a pointer store).
+ * Not written by os2r_rollout.  NULL switches it off.                                                                     */
+OS2R_API int os2r_set_done_mask(Os2rSim* sim, uint8_t* mask_dev);
 
 OS2R_API const char* os2r_last_error(Os2rSim* sim); /* sim == NULL: error of the last failed create */
 

@@ -15,29 +15,61 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libos2r_oracle.so")
-    src = os.path.join(_HERE, "os2r_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+def build(force: bool = False, lab: bool = False) -> str:
+    """Build the checker (libos2r_oracle.so) or, lab=True, the laboratory (liboracle_lab.so: the same source with
+    -DORC_EXPERIMENTS, i.e. with the experimental switches of the solver studies; tests/diag and docs/studies only)."""
+    so = os.path.join(_HERE, "liboracle_lab.so" if lab else "libos2r_oracle.so")
+    deps = [os.path.join(_HERE, "os2r_oracle.c"), os.path.join(_HERE, "os2r_oracle.h"), os.path.join(_HERE, "..", "include", "os2r.h")]
+    if force or not os.path.exists(so) or any(os.path.exists(d) and os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + (["lab"] if lab else []))
     return so
 
 
+def _bind(so):
+    L = C.CDLL(so)
+    L.orc_tolerance.restype = C.c_double
+    L.orc_tolerance.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+    L.orc_wrap.restype = C.c_double
+    L.orc_wrap.argtypes = [C.c_double]
+    L.orc_reward.restype = C.c_double
+    L.orc_get_step_count.restype = C.c_uint64
+    L.orc_set_step_count.argtypes = [C.c_void_p, C.c_uint64]
+    return L
+
+
 def lib():
+    """The library the module's functions call: the checker, unless inside `with laboratory():`."""
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libos2r_oracle.so")
-        if not os.path.exists(so):
-            build()
-        _LIB = C.CDLL(so)
-        _LIB.orc_tolerance.restype = C.c_double
-        _LIB.orc_tolerance.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
-        _LIB.orc_wrap.restype = C.c_double
-        _LIB.orc_wrap.argtypes = [C.c_double]
-        _LIB.orc_reward.restype = C.c_double
-        _LIB.orc_get_step_count.restype = C.c_uint64
-        _LIB.orc_set_step_count.argtypes = [C.c_void_p, C.c_uint64]
+        _LIB = _bind(build())
     return _LIB
+
+
+_LAB = None
+
+
+class laboratory:
+    """`with oracle_py.laboratory() as L:` -- inside, the module's functions and every OracleSim created use the
+    laboratory build (its experimental switches: L.orc_set_experimental_*); an OracleSim keeps the library it was created
+    with.  Studies and diagnostics only: the parity tests, smoke() and the CPU baseline use the checker, which has no switch."""
+
+    def __enter__(self):
+        global _LIB, _LAB
+        if _LAB is None:
+            _LAB = _bind(build(lab=True))
+            _LAB.orc_debug_counter.restype = C.c_longlong
+        self._saved, _LIB = _LIB, _LAB
+        return _LAB
+
+    def __exit__(self, *exc):
+        global _LIB
+        _LIB = self._saved
+        return False
+
+
+def use_laboratory():
+    """Switch this process to the laboratory build for good (tests/diag scripts); -> the library."""
+    return laboratory().__enter__()
 
 
 def _p(a):
@@ -168,15 +200,16 @@ class OracleSim:
         self.N = int(cfg.num_envs)
         self.nq = int(cfg.model.nq)
         self.D = int(cfg.task.obs_dim)
+        self._L = lib()                                  # (the checker, or the laboratory inside `with laboratory():`)
         self._h = C.c_void_p()
-        rc = lib().orc_create(C.byref(cfg), C.byref(self._h))
+        rc = self._L.orc_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             raise RuntimeError(f"orc_create failed: {rc}")
-        lib().orc_set_threads(self._h, int(threads))
+        self._L.orc_set_threads(self._h, int(threads))
 
     def set_contact_model(self, model: int):
         """CONTACT_CENTROID (the specification, default) or CONTACT_PER_VERTEX (comparison model)."""
-        lib().orc_set_contact_model(self._h, int(model))
+        self._L.orc_set_contact_model(self._h, int(model))
 
     def solver_counts(self):
         """Diagnostics: (sweeps, solves), int8 [substeps, N] -- the phase-2 sweeps and exact solves of every physics
@@ -184,20 +217,20 @@ class OracleSim:
         n = int(self.cfg.substeps)
         sw = np.zeros((n, self.N), dtype=np.int8)
         so = np.zeros((n, self.N), dtype=np.int8)
-        if lib().orc_get_solver_counts(self._h, _p(sw), _p(so)):
+        if self._L.orc_get_solver_counts(self._h, _p(sw), _p(so)):
             return None
         return sw, so
 
     def small_solve_counts(self):
         """int8 [substeps, N]: how many of the exact solves of solver_counts() were dual solves of a small free set."""
         sm = np.zeros((int(self.cfg.substeps), self.N), dtype=np.int8)
-        if lib().orc_get_small_solve_counts(self._h, _p(sm)):
+        if self._L.orc_get_small_solve_counts(self._h, _p(sm)):
             return None
         return sm
 
     def close(self):
         if self._h:
-            lib().orc_destroy(self._h)
+            self._L.orc_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -209,66 +242,66 @@ class OracleSim:
     def reset(self, mask=None):
         obs = np.zeros((self.N, self.D))
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        lib().orc_reset(self._h, _p(m), _p(obs))
+        self._L.orc_reset(self._h, _p(m), _p(obs))
         return obs
 
     def step(self, actions=None):
         a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
         obs, term = np.zeros((self.N, self.D)), np.zeros((self.N, self.D))
         rew, done_ = np.zeros(self.N), np.zeros(self.N, dtype=np.uint8)
-        lib().orc_step(self._h, _p(a), _p(obs), _p(rew), _p(done_), _p(term))
+        self._L.orc_step(self._h, _p(a), _p(obs), _p(rew), _p(done_), _p(term))
         return obs, rew, done_, term
 
     def get_state(self):
         q, qd = np.zeros((self.nq, self.N)), np.zeros((self.nq, self.N))
-        lib().orc_get_state(self._h, _p(q), _p(qd))
+        self._L.orc_get_state(self._h, _p(q), _p(qd))
         return q, qd
 
     def set_state(self, q, qd):
         q = np.ascontiguousarray(q, dtype=np.float64)
         qd = np.ascontiguousarray(qd, dtype=np.float64)
         assert q.shape == (self.nq, self.N) and qd.shape == (self.nq, self.N)
-        lib().orc_set_state(self._h, _p(q), _p(qd))
+        self._L.orc_set_state(self._h, _p(q), _p(qd))
 
     def get_solver_state(self):
         """(lam [4*nq, N], flags uint32 [N]): the impulses that ended every environment's last physics iteration, in the
         layout of os2r_get_solver_state (include/os2r.h)."""
         lam, flags = np.zeros((4 * self.nq, self.N)), np.zeros(self.N, dtype=np.uint32)
-        lib().orc_get_solver_state(self._h, _p(lam), _p(flags))
+        self._L.orc_get_solver_state(self._h, _p(lam), _p(flags))
         return lam, flags
 
     def set_solver_state(self, lam, flags):
         lam = np.ascontiguousarray(lam, dtype=np.float64)
         flags = np.ascontiguousarray(flags, dtype=np.uint32)
         assert lam.shape == (4 * self.nq, self.N) and flags.shape == (self.N,)
-        lib().orc_set_solver_state(self._h, _p(lam), _p(flags))
+        self._L.orc_set_solver_state(self._h, _p(lam), _p(flags))
 
     def get_action_history(self, which):
         out = np.zeros((2, self.N))
-        lib().orc_get_action_history(self._h, int(which), _p(out))
+        self._L.orc_get_action_history(self._h, int(which), _p(out))
         return out
 
     def set_action_history(self, which, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         assert arr.shape == (2, self.N)
-        lib().orc_set_action_history(self._h, int(which), _p(arr))
+        self._L.orc_set_action_history(self._h, int(which), _p(arr))
 
     def get_params(self, field):
         count = 1 if field == 4 else self.nq
         out = np.zeros((count, self.N))
-        lib().orc_get_params(self._h, int(field), _p(out))
+        self._L.orc_get_params(self._h, int(field), _p(out))
         return out
 
     def set_params(self, field, arr):
         count = 1 if field == 4 else self.nq
         arr = np.ascontiguousarray(arr, dtype=np.float64).reshape(count, self.N)
-        lib().orc_set_params(self._h, int(field), _p(arr))
+        self._L.orc_set_params(self._h, int(field), _p(arr))
 
     def episode_info(self):
         steps = np.zeros(self.N, dtype=np.int32)
         epi = np.zeros(self.N, dtype=np.uint32)
         pose = np.zeros(self.N, dtype=np.uint8)
-        lib().orc_get_episode_info(self._h, _p(steps), _p(epi), _p(pose))
+        self._L.orc_get_episode_info(self._h, _p(steps), _p(epi), _p(pose))
         return steps, epi, pose
 
     def set_episode_info(self, steps=None, episode=None, pose=None):
@@ -276,15 +309,15 @@ class OracleSim:
              None if episode is None else np.ascontiguousarray(episode, dtype=np.uint32),
              None if pose is None else np.ascontiguousarray(pose, dtype=np.uint8)]
         assert all(x is None or x.shape == (self.N,) for x in a)
-        lib().orc_set_episode_info(self._h, _p(a[0]), _p(a[1]), _p(a[2]))
+        self._L.orc_set_episode_info(self._h, _p(a[0]), _p(a[1]), _p(a[2]))
 
     def set_step_count(self, v):
         self.step_count = v
 
     @property
     def step_count(self):
-        return int(lib().orc_get_step_count(self._h))
+        return int(self._L.orc_get_step_count(self._h))
 
     @step_count.setter
     def step_count(self, v):
-        lib().orc_set_step_count(self._h, C.c_uint64(int(v)))
+        self._L.orc_set_step_count(self._h, C.c_uint64(int(v)))

@@ -561,8 +561,42 @@ static int build_problem(const Os2rConfig* cfg, int contact_model, const EnvPara
  * contact are minimised over exactly as a block (enumeration of the active sets of the 3-variable box QP, first
  * assignment that meets the optimality conditions) instead of row by row.  Measures what an exact per-contact
  * block would buy in closed loop before anything of the kind is built for the GPU. */
-static int g_block_solve = 0;
+/* ---- the laboratory (ORC_EXPERIMENTS) ----
+ * The solver studies of rounds 3-5 (docs/studies/) run on switches that change what the solver below does.  They exist ONLY in
+ * the laboratory build (make lab -> liboracle_lab.so, -DORC_EXPERIMENTS; used by tests/diag/ and the studies): in the checker
+ * (libos2r_oracle.so: what tests/, smoke() and bench.py's cpu_baseline load) every one of them is the compile-time constant of
+ * the specification, no setter is exported and the experimental branches are dead code. */
+#ifdef ORC_EXPERIMENTS
+static int g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = 0, g_incons_once = 0, g_lag_box = 0;
+static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0;
+static double g_incons = 1e-4, g_stall = 0.0;
+static int g_trace = -1;                 /* ORC_TRACE_SOLVES=k in the environment: iterations with k or more solves are printed */
+static long long g_dbg_counter[4];       /* orc_debug_counter: [0] warm-started iterations, [1] of those with an active row that has no remembered impulse */
+static int g_dbg_on = 0;
 void orc_set_experimental_block_solve(int on) { g_block_solve = on; }
+void orc_set_experimental_block_kind(int kind) { g_block_kind = kind; }   /* 0: enumeration of the block's active sets, 1: Gauss-Seidel pass + one exact solve of the rows left free, 2: the pair update */
+void orc_set_experimental_row_order(int order) { g_row_order = order; }
+void orc_set_experimental_prox(int k) { g_prox = k; }
+void orc_set_experimental_incons(double v) { g_incons = v; }
+void orc_set_experimental_clamp_all(int on) { g_clamp_all = on; }
+void orc_set_experimental_small(int on) { g_small = on; }
+void orc_set_experimental_incons_once(int n) { g_incons_once = n; }
+void orc_set_experimental_lag_box(int on) { g_lag_box = on; }
+void orc_set_experimental_stall(double factor) { g_stall = factor < 0 ? -factor : factor; g_stall_incons_only = factor < 0; }   /* < 0: only rounds with an inconsistent-set step */
+void orc_set_experimental_sweep_after_cut(int on) { g_sweep_after_cut = on; }
+void orc_set_experimental_rounds(int max_rounds, int stop_at_cap) { g_max_rounds = max_rounds; g_stop_at_cap = stop_at_cap; }
+/* first > 0: that many sweeps before the first check; first = -k: k - 1 sweeps, then EVERY environment solves once before its first check */
+void orc_set_experimental_warm(int mode, int first) {
+  g_warm = mode; g_first = first > 0 ? first : (first < 0 ? -first - 1 : 3); g_solve_always = first < 0;
+}
+long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
+#else
+enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = 0, g_incons_once = 0, g_lag_box = 0,
+       g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
+       g_trace = 0, g_dbg_on = 0 };
+static const double g_incons = 1e-4, g_stall = 0.0;
+#endif
+
 
 static int solve_sub(const double A[3][3], const double c[3], const int* idx, int m, double* mu) {
   /* A_FF mu_F = -c_F for the m free variables idx[0..m) by Cramer's rule; 0 if singular */
@@ -634,8 +668,6 @@ static int block_update(int n, Row* rows, int r0, double* v, double* moved) {
  * impulse space (the block's Gram matrix A = G G^T, residuals w), then ONE exact solve of the rows that pass left strictly
  * inside their box, the others held where the pass put them; the result is taken if it stays inside the box, else the
  * pass stands.  Exact whenever the pass identifies the block's active set, which a warm start nearly always does. */
-static int g_block_kind = 0;
-void orc_set_experimental_block_kind(int kind) { g_block_kind = kind; }
 static int block_update_cheap(int n, Row* rows, int r0, double* v, double* moved) {
   Row* R[3] = {&rows[r0], &rows[r0 + 1], &rows[r0 + 2]};
   for (int i = 0; i < 3; ++i) if (!(R[i]->d > 0.0)) return 0;
@@ -728,8 +760,6 @@ static int block_update_pair(int n, Row* rows, int r0, double* v, double* moved)
 
 /* EXPERIMENT (oracle only, off by default): order of the three rows of a contact inside a phase-2 sweep.
  * 0: normal, x, y (the specification)   1: y, x, normal   2: the less mobile tangential row, the other, normal */
-static int g_row_order = 0;
-void orc_set_experimental_row_order(int order) { g_row_order = order; }
 
 /* ---- exact finish of the fixed-box problem (cfg->pgs_exact) ----
  * Gauss-Seidel identifies the active set of most problems within a few sweeps and then crawls on the few whose rows
@@ -749,8 +779,6 @@ void orc_set_experimental_row_order(int order) { g_row_order = order; }
 #define ORC_EXACT_FIRST(n) (cold_now ? ORC_EXACT_FIRST_COLD(n) : g_first)   /* sweeps before the first check */
 #define ORC_EXACT_EPS 1e-6
 #define ORC_EXACT_PROX g_prox
-static int g_prox = 3;   /* (orc_set_experimental_prox: studies) */
-void orc_set_experimental_prox(int k) { g_prox = k; }
 #define ORC_EXACT_SNAP 1e-12
 /* A free set can be INCONSISTENT: more sticking rows than the degrees of freedom they act on (four or five of them on
  * the three dof of `monopod-fixed`, two sticking contacts in five dof).  The solve then ends at the least-squares point
@@ -760,8 +788,6 @@ void orc_set_experimental_prox(int k) { g_prox = k; }
  * ORC_EXACT_INCONS of what it found (squared norms), it goes on in the direction of its multipliers -- past the full
  * step -- to the first bound it meets, sets that row on it and solves again, as after a cut. */
 #define ORC_EXACT_INCONS g_incons
-static double g_incons = 1e-4;   /* (orc_set_experimental_incons: studies) */
-void orc_set_experimental_incons(double v) { g_incons = v; }
 /* EXPERIMENT (oracle only, off by default; docs/studies/round4_solver.md): small free sets solved in the dual.  In the
  * regimes the stepper lives in, an environment that needs a solve has two free rows -- the normal and one tangential row
  * of a sticking-sliding contact, or the normals of two contacts -- seldom three and hardly ever more (joints slide: their
@@ -775,10 +801,6 @@ void orc_set_experimental_incons(double v) { g_incons = v; }
  * it and the specification stays with the one solve. */
 #define ORC_EXACT_SMALL 3
 #define ORC_EXACT_SMALL_PIVOT 1e-8
-static int g_clamp_all = 0;
-void orc_set_experimental_clamp_all(int on) { g_clamp_all = on; }
-static int g_small = 0;   /* (orc_set_experimental_small: studies -- 1 switches the dual solve of small free sets on) */
-void orc_set_experimental_small(int on) { g_small = on; }
 static _Thread_local int tl_last_small = 0;   /* diagnostics: dual solves among the solves of the last iteration */
 
 static void chol_lower(int n, const double* a, double* l) {   /* a = l l^T, row-major n x n */
@@ -803,7 +825,6 @@ static void row_box(const Row* rows, const Row* R, int fixed_box, double* lo, do
 
 /* diagnostics (ORC_TRACE_SOLVES=k in the environment: iterations with k or more solves are printed, solve by solve:
  * the free set by row kind -- n normal, t tangential, j joint, lower case; upper case = the row the step ended on) */
-static int g_trace = -1;
 static _Thread_local char tl_trace[4096];
 static _Thread_local int tl_trace_len = 0;
 static void trace_sweep(double moved) {
@@ -828,9 +849,36 @@ static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu
   tl_trace_len = (int)(b - tl_trace);
 }
 
-static int g_incons_once = 0;
-void orc_set_experimental_incons_once(int n) { g_incons_once = n; }
 static _Thread_local int tl_incons_steps = 0;   /* steps to the first bound of an inconsistent free set taken so far in this iteration */
+#ifdef ORC_EXPERIMENTS
+/* laboratory diagnostics (orc_debug_free_set_hist): the shape of the free set of every exact solve, by the solve's index within its
+ * physics iteration (0 .. 15) -- class 0: the normal and ONE tangential row of one contact, 1: two normals, 2: one row, 3: the three
+ * rows of one contact, 4: any other set of at most three rows, 5: four rows or more; +6 when a joint row is among them */
+static long long g_fs_hist[16][12];
+static _Thread_local int tl_solve_index = 0;
+void orc_debug_free_set_hist(long long* out, int reset) {
+  memcpy(out, g_fs_hist, sizeof(g_fs_hist));
+  if (reset) memset(g_fs_hist, 0, sizeof(g_fs_hist));
+}
+static void note_free_set(const Row* rows, int nr, const int* fr) {
+  int m = 0, nn = 0, nt = 0, nj = 0, bodies = 0, last_body = -1;
+  for (int r = 0; r < nr; ++r) {
+    if (!fr[r]) continue;
+    ++m;
+    if (rows[r].kind == 0) ++nn; else if (rows[r].kind == 1) ++nt; else ++nj;
+    if (rows[r].kind != 2 && rows[r].body != last_body) { ++bodies; last_body = rows[r].body; }
+  }
+  int c;
+  if (m == 2 && nn == 1 && nt == 1 && bodies == 1) c = 0;
+  else if (m == 2 && nn == 2) c = 1;
+  else if (m == 1) c = 2;
+  else if (m == 3 && nn == 1 && nt == 2 && bodies == 1) c = 3;
+  else if (m <= 3) c = 4;
+  else c = 5;
+  if (nj) c += 6;
+  __atomic_fetch_add(&g_fs_hist[tl_solve_index < 15 ? tl_solve_index : 15][c], 1, __ATOMIC_RELAXED);
+}
+#endif
 /* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
 static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int test_consistency) {
   double g[3 * OS2R_MAX_DOF + OS2R_MAX_DOF][OS2R_MAX_DOF], w[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
@@ -849,6 +897,9 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
   }
   for (int i = 0; i < n; ++i) tr += S[i][i];
   if (!(tr > 0.0)) return 0;                       /* no free row: nothing to solve */
+#ifdef ORC_EXPERIMENTS
+  if (g_dbg_on) note_free_set(rows, nr, fr);
+#endif
   /* ---- a small, well-conditioned free set: the dual solve ---- */
   {
     int F[ORC_EXACT_SMALL], m = 0, small = g_small;
@@ -1017,23 +1068,7 @@ static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 #define ORC_WARM_FIRST 3
 #define ORC_WARM_ROWS (3 * OS2R_MAX_DOF + OS2R_MAX_DOF)
 #define ORC_WARM_SLOTS (ORC_WARM_ROWS + 1)   /* the last slot: 1.0 once an iteration has left its impulses (the joint rows are remembered) */
-static long long g_dbg_counter[4];   /* diagnostics (orc_debug_counter): [0] warm-started iterations, [1] of those with an active row that has no remembered impulse */
-static int g_dbg_on = 0;
-long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
-static int g_lag_box = 0;   /* (orc_set_experimental_lag_box: studies -- 1: the lagged friction box, docs/studies/round4_solver.md) */
-void orc_set_experimental_lag_box(int on) { g_lag_box = on; }
-static int g_warm = 1, g_first = ORC_WARM_FIRST, g_solve_always = 0;
-static double g_stall = 0.0;
-static int g_stall_incons_only = 0;
-void orc_set_experimental_stall(double factor) { g_stall = factor < 0 ? -factor : factor; g_stall_incons_only = factor < 0; }   /* < 0: only rounds with an inconsistent-set step */
-static int g_sweep_after_cut = 0;   /* experiment: a step that a bound cut short is followed by a sweep (which may clamp several rows at once), not by the next solve */
-void orc_set_experimental_sweep_after_cut(int on) { g_sweep_after_cut = on; }
-static int g_max_rounds = 0, g_stop_at_cap = 0;   /* experiment: an environment ends phase 2 after that many (solves, re-test sweep) rounds / when its solves are spent */
-void orc_set_experimental_rounds(int max_rounds, int stop_at_cap) { g_max_rounds = max_rounds; g_stop_at_cap = stop_at_cap; }
 /* first > 0: that many sweeps before the first check; first = -k: k - 1 sweeps, then EVERY environment solves once before its first check */
-void orc_set_experimental_warm(int mode, int first) {
-  g_warm = mode; g_first = first > 0 ? first : (first < 0 ? -first - 1 : ORC_WARM_FIRST); g_solve_always = first < 0;
-}
 static _Thread_local double tl_warm[ORC_WARM_SLOTS];
 static _Thread_local int tl_cold = 0;   /* modes 0 and 2 only */
 static void warm_forget(double* w) { for (int k = 0; k < ORC_WARM_SLOTS; ++k) w[k] = NAN; }
@@ -1081,10 +1116,14 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
     if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS) {
       int fresh = 0;   /* diagnostics: an active row without a remembered impulse (a new contact, the iteration after a reset) */
       if (g_dbg_on) for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0 && isnan(tl_warm[warm_slot(rows, r)])) fresh = 1;
+#ifdef ORC_EXPERIMENTS
       if (g_dbg_on) {   /* (shared counters: switched on by the first orc_debug_counter call only -- sixteen threads on one cache line halve the oracle's speed) */
         __atomic_fetch_add(&g_dbg_counter[0], 1, __ATOMIC_RELAXED);
         if (fresh) __atomic_fetch_add(&g_dbg_counter[1], 1, __ATOMIC_RELAXED);
       }
+#else
+      (void)fresh;
+#endif
     }
     if (phase == 1 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS)
       for (int r = 0; r < nr; ++r) {
@@ -1101,13 +1140,20 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
     if (phase == 1) tl_incons_steps = 0;
     double e_prev = -1.0;
     if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; tl_last_small = 0; tl_trace_len = 0; }
+#ifdef ORC_EXPERIMENTS
     if (g_trace < 0) { const char* t = getenv("ORC_TRACE_SOLVES"); g_trace = t ? atoi(t) : 0; }
+#endif
     for (int it = 0; it < sweeps; ++it) {
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
       if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST(n) && solves < exact) {
         int blocked = 1;
-        while (blocked && solves < exact) { blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; if (g_sweep_after_cut) break; }
+        while (blocked && solves < exact) {
+#ifdef ORC_EXPERIMENTS
+          tl_solve_index = solves;
+#endif
+          blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; if (g_sweep_after_cut) break;
+        }
         tl_last_solves = solves;
         ++rounds;
       }
@@ -1367,6 +1413,7 @@ int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves) {
   if (solves) memcpy(solves, s->solver_counts + n, n);
   return 0;
 }
+#ifdef ORC_EXPERIMENTS
 /* (recording on:) how many of those solves were dual solves of a small free set */
 int orc_get_small_solve_counts(OrcSim* s, int8_t* small) {
   const size_t n = (size_t)s->cfg.substeps * s->N;
@@ -1374,6 +1421,7 @@ int orc_get_small_solve_counts(OrcSim* s, int8_t* small) {
   memcpy(small, s->solver_counts + 2 * n, n);
   return 0;
 }
+#endif
 
 static void observe_env(const OrcSim* s, int64_t e, double* obs) {
   const int n = s->cfg.model.nq; const int64_t N = s->N;

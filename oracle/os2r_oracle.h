@@ -49,11 +49,15 @@ void orc_destroy(OrcSim* s);
 void orc_set_threads(OrcSim* s, int n);
 void orc_set_contact_model(OrcSim* s, int model);
 int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves);   /* diagnostics: [substeps][N] each, of the last step; the first call switches recording on */
+#ifdef ORC_EXPERIMENTS
+/* The laboratory build only (make lab -> liboracle_lab.so; tests/diag/ and the studies under docs/studies/): switches that change
+ * what the solver does.  The checker library (libos2r_oracle.so) has none of them: there they are the specification's constants. */
 int orc_get_small_solve_counts(OrcSim* s, int8_t* small);               /* of those solves: the dual solves of small free sets */
 void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
 void orc_set_experimental_row_order(int order);
 void orc_set_experimental_rounds(int max_rounds, int stop_at_cap);
 long long orc_debug_counter(int which, int reset);   /* diagnostics, see os2r_oracle.c */
+void orc_debug_free_set_hist(long long* out16x12, int reset);   /* diagnostics: free-set shapes by solve index (the first orc_debug_counter call switches recording on) */
 void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged friction box (no phase 1 for an environment that remembers every active row) */
 void orc_set_experimental_incons(double threshold);   /* studies: the inconsistent-free-set test's threshold (1e-4) */
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
@@ -64,6 +68,7 @@ void orc_set_experimental_clamp_all(int on);
 void orc_set_experimental_block_kind(int kind);   /* 0: enumeration of the block's active sets, 1: Gauss-Seidel pass + one exact solve of the rows left free */
 void orc_set_experimental_warm(int mode, int first);  /* studies: 1 the specification, 0 no warm start, 2 round 3 (forgotten between env-steps); K sweeps before the first check */
 void orc_set_experimental_small(int on);   /* studies: 1 switches the dual solve of small free sets on (off: every solve is the regularised one) */
+#endif
 int orc_get_solver_state(OrcSim* s, double* lam, uint32_t* flags);   /* layout of os2r_get_solver_state (include/os2r.h) */
 int orc_set_solver_state(OrcSim* s, const double* lam, const uint32_t* flags);
 int orc_reset(OrcSim* s, const uint8_t* mask, double* obs);

@@ -10,7 +10,7 @@ class A:
     workload=wl; envs_per_gpu=8192; dtype="f64"; seed=42
     pgs_iters=None; pgs_normal_iters=3; pgs_tol=None; pgs_exact=None; runtime_model=False
 cfg,_,_=bench.build_config(A,0,1)
-O.build(); O.lib().orc_set_experimental_warm(mode,0)
+O.use_laboratory().orc_set_experimental_warm(mode,0)   # the laboratory build: oracle/Makefile
 o=O.OracleSim(cfg,threads=8)
 for _ in range(400): o.step(None)
 o.solver_counts()

@@ -272,7 +272,7 @@ def study_closedloop(mode, dr, steps):
     # to p90 8.5e-8 after 1000 balancing env-steps with DR, the 3 + 2000-sweep solve that served as yardstick in round 2
     # only to p90 1.6e-5)
     ref = run(pgs_iters=300, pgs_exact=100, pgs_tol=0.0)
-    L = O.lib()
+    L = O.use_laboratory()   # the laboratory build (oracle/Makefile): the experimental switches exist there only
     S0 = dict(pgs_exact=0)                                        # sweeps only (rounds 1-2)
     for name, blk, kw in [("exact finish (default: 3+12, 12 solves)", 0, {}), ("exact finish, 6 solves", 0, dict(pgs_exact=6)), ("exact finish, 3 solves", 0, dict(pgs_exact=3)),
                           ("exact finish, 1 solve, 20 sweeps", 0, dict(pgs_exact=1, pgs_iters=20)),

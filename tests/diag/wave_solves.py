@@ -39,8 +39,8 @@ def main():
         workload = a.workload; envs_per_gpu = a.envs; dtype = "f64"; seed = 42
         pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
-    O.build()
-    O.lib().orc_set_experimental_warm(int(a.warm), int(a.first))
+    L = O.use_laboratory()   # the laboratory build (oracle/Makefile)
+    L.orc_set_experimental_warm(int(a.warm), int(a.first))
     o = O.OracleSim(cfg, threads=os.cpu_count() or 1)
     for _ in range(a.preroll):
         o.step(None)
@@ -75,7 +75,7 @@ def main():
         am = so[:, w, :].argmax(axis=1)
         lane = np.bincount(am).argmax()
         print(f"  wave {w}: {tot[w]} solves; per iteration {so[:, w, :].max(axis=1)}; driven by lanes {am}; lane {lane}: solves {so[:, w, lane]} sweeps {sw[:, w, lane]}")
-    O.lib().orc_set_experimental_warm(1, 0)
+    L.orc_set_experimental_warm(1, 0)
 
 
 if __name__ == "__main__":

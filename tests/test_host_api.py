@@ -213,6 +213,29 @@ def test_capi_library_exports_every_declared_symbol():
     assert b"null config" in _lib.load().os2r_last_error(None)
 
 
+def test_the_checker_oracle_has_no_experimental_switch(oracle):
+    """The oracle that the parity tests, smoke() and the CPU baseline load is the checker build: the switches of the solver studies
+    (orc_set_experimental_*, the solve traces, the debug counters) exist in the laboratory build only (oracle/Makefile: `make lab`,
+    -DORC_EXPERIMENTS), so no test can run against a specification that an earlier test or study left switched.
+    And the product's device code carries no timing-only experiment of the solver either."""
+    import shutil
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "libos2r_oracle.so")
+    assert os.path.exists(so)
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert names and not [n for n in names if "experimental" in n or "debug_counter" in n], names
+    assert not hasattr(oracle.lib(), "orc_set_experimental_warm")
+    with oracle.laboratory() as lab:                  # the laboratory is a second library; the checker stays what lib() returns
+        assert hasattr(lab, "orc_set_experimental_warm")
+    assert not hasattr(oracle.lib(), "orc_set_experimental_warm")
+    for name in ("os2r_device.hpp", "os2r_kernels.hpp"):
+        with open(os.path.join(ROOT, "gym-os2r_amd", "csrc", name)) as f:
+            src = f.read()
+        assert "OS2R_PAIR_FIX" not in src and "OS2R_WARM_FIRST" not in src, name
+
+
 def test_model_compiler_on_a_synthetic_urdf(tmp_path):
     """Fixed-joint lumping, literal rpy, composite inertia: checked on a hand-computable chain."""
     urdf = tmp_path / "toy.urdf"

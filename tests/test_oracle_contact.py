@@ -343,10 +343,11 @@ def test_warm_start_between_iterations_saves_sweeps_and_changes_nothing(oracle):
     n = 2048
     cfg, task, model = make_config("free_hip", num_envs=n, reset_mode=abi.RESET_RANDOM, randomize_params=True, max_episode_steps=100000,
                                    seed=42, contact=True)
-    a = oracle.OracleSim(cfg, threads=8)
+    a = oracle.OracleSim(cfg, threads=8)               # the checker: the specification
     for _ in range(400):
         a.step(None)
-    b = oracle.OracleSim(cfg, threads=8)
+    with oracle.laboratory() as lab:                   # the cold variant exists in the laboratory build only (oracle/Makefile)
+        b = oracle.OracleSim(cfg, threads=8)
     b.set_state(*a.get_state())
     for f in range(5):
         b.set_params(f, a.get_params(f))
@@ -355,8 +356,8 @@ def test_warm_start_between_iterations_saves_sweeps_and_changes_nothing(oracle):
     b.set_step_count(a.step_count)
     counts = {}
     try:
+        lab.orc_set_experimental_warm(0, 0)
         for sim, on in ((a, 1), (b, 0)):
-            oracle.lib().orc_set_experimental_warm(on, 0)
             sim.solver_counts()
             cnt = np.zeros(4, dtype=np.int64)
             for _ in range(3):
@@ -365,7 +366,7 @@ def test_warm_start_between_iterations_saves_sweeps_and_changes_nothing(oracle):
                 cnt += np.array([(so >= 1).sum(), (so >= 2).sum(), so.sum(), sw.astype(np.int64).sum()])
             counts[on] = cnt
     finally:
-        oracle.lib().orc_set_experimental_warm(1, 0)
+        lab.orc_set_experimental_warm(1, 0)
     qa, va = a.get_state(); qb, vb = b.get_state()
     err = max(np.max(np.abs(qa - qb) / np.maximum(np.abs(qb), 1.0)), np.max(np.abs(va - vb) / np.maximum(np.abs(vb), 1.0)))
     print(f"[warm start] env-iterations with a solve / with two or more / solves in all / phase-2 sweeps in all: warm {counts[1]}, cold {counts[0]}; "
