@@ -97,6 +97,104 @@ def algorithmic_bytes_per_env_step(cfg, esz):
     return reads + writes
 
 
+def survey_bytes_per_env_step(cfg, esz):
+    """SURVEY.md 8(d)'s own count of the algorithmic bytes: reads q, qd, action, previous action, per-env parameters; writes q, qd,
+    obs, reward, done (1 B), current action -- 125 / 149 / 233 B for C2 / C3 / C4 in fp32, twice that (minus the flag byte) in fp64.
+    What the launch moves beyond it (terminal observation, counters, the contact solver's state in and out: `algorithmic_bytes_per_env_step`)
+    is the builder's addition to the environment's state and outputs, not part of the survey's yardstick."""
+    nq, D = cfg.model.nq, cfg.task.obs_dim
+    P = 4 * nq + 1 if cfg.task.reset_mode == 1 else 0
+    return (2 * nq + 2 + 2 + P) * esz + (2 * nq + D + 1 + 2) * esz + 1
+
+
+def gym_level(args, cfg_bench, ck, value):
+    """The surface users call (replaces gym_os2r/runtimes/gazebo_runtime.py:65-97): env-steps/s through
+    `HipRuntime.step(actions)` behind the randomizer wrapper -- Python, ctypes marshalling, fresh output tensors per step, the
+    action check, info -- on the bench workload, continued from the timed window's checkpoint (the same stationary regime), with a
+    fresh U(-1, 1) device action tensor per step (views of one pre-generated block: what a policy hands over, without a policy's
+    kernels), bracketed by synchronize like the headline.  Plus the host's own cost per call, measured with the GPU idle (64
+    environments, the queue allowed to run deep so that nothing waits)."""
+    import functools
+    import torch
+    from gym_os2r_amd import rewards
+    from gym_os2r_amd.common import make_env_from_id
+    from gym_os2r_amd.randomizers.monopod import MonopodEnvRandomizer
+    from gym_os2r_amd.randomizers.monopod_no_rand import MonopodEnvNoRandomizer
+    mode, reward, contact, dr, _ = WORKLOADS[args.workload]
+    env_id = {"free_hip": "Monopod-hop-v1", "fixed_hip": "Monopod-stand-v1", "fixed_hip_simple": "Monopod-balance-v1"}[mode]
+    wrapper = MonopodEnvRandomizer if dr else MonopodEnvNoRandomizer
+
+    def make(n):
+        env = wrapper(env=functools.partial(make_env_from_id, env_id=env_id, num_envs=n, seed=args.seed, contact=contact,
+                                            reward_class=getattr(rewards, reward), reset_positions=["stand"], max_episode_steps=100_000,
+                                            dtype=args.dtype, pgs_iters=args.pgs_iters, pgs_normal_iters=args.pgs_normal_iters,
+                                            pgs_tol=args.pgs_tol, pgs_exact=getattr(args, "pgs_exact", None)))
+        env.reset()
+        return env
+    n = args.envs_per_gpu
+    env = make(n)
+    sim = env.unwrapped.sim
+    if ck is not None:                                # the stationary regime the headline was timed in
+        if not dr:                                    # (restoring parameters would switch a nominal handle to per-env ones)
+            ck = {k_: v_ for k_, v_ in ck.items() if k_ != "params"}
+            ck["params"] = {}
+        sim.restore(ck)
+    else:
+        sim.bench_steps(max(args.preroll, 1))
+    K = max(10, min(args.steps, 300))
+    warm = 10
+    acts = torch.rand(K + warm, n, 2, dtype=sim.dtype, device=sim.device) * 2 - 1
+    for k in range(warm):
+        env.step(acts[k])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(warm, warm + K):
+        obs, rew, done, info = env.step(acts[k])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.close()
+    small = make(64)
+    small.unwrapped.max_inflight = 1 << 30            # nothing waits: what is timed is the host
+    a64 = torch.rand(400, 64, 2, dtype=sim.dtype, device=sim.device) * 2 - 1
+    for k in range(50):
+        small.step(a64[k])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for k in range(50, 400):
+        small.step(a64[k])
+    host = (time.perf_counter() - t1) / 350
+    torch.cuda.synchronize()
+    small.close()
+    v = n * K / dt
+    return {"value": v, "unit": "env-steps/s", "frac_of_value": v / value, "us_per_step": dt / K * 1e6, "steps": K,
+            "host_us_per_call": host * 1e6,
+            "surface": "MonopodEnvRandomizer(HipRuntime).step(actions[N, 2] device tensor) -> obs, reward, done, info: fresh output tensors per "
+                       "step, done mask and action check from the step launch itself (ABI 5): one kernel launch per call",
+            "actions": "a fresh U(-1,1) device tensor per step (pre-generated: no policy kernels)",
+            "host_us_per_call_note": "64 environments, GPU idle, run-ahead unbounded: Python + ctypes + torch.empty + the HIP enqueue"}
+
+
+def rollout_line(args, sim, K=10):
+    """The separate open-loop line (never the headline): K env-steps per launch (os2r_rollout), continued from where the handle is."""
+    import torch
+    n_l = max(1, min(args.steps, 1000) // K)
+    obs_k = torch.empty(K, sim.N, sim.D, dtype=sim.dtype, device=sim.device)
+    term_k = torch.empty_like(obs_k)
+    rew_k = torch.empty(K, sim.N, dtype=sim.dtype, device=sim.device)
+    done_k = torch.empty(K, sim.N, dtype=torch.uint8, device=sim.device)
+    for _ in range(2):
+        sim.rollout_into(K, None, obs_k, rew_k, done_k, term_k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_l):
+        sim.rollout_into(K, None, obs_k, rew_k, done_k, term_k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"K": K, "value": sim.N * K * n_l / dt, "unit": "env-steps/s", "us_per_env_step_of_the_batch": dt / (K * n_l) * 1e6, "launches": n_l,
+            "note": "open-loop rollouts, K env-steps per launch (os2r_rollout: no device-wide barrier between the env-steps), every "
+                    "output of every step written; a separate line, never the headline"}
+
+
 def host_cores():
     """Cores this process may actually use: the affinity mask, cut down to the cgroup's CPU quota (a GPU box hands a
     container a share of the host -- 16 cores per GPU on this pool -- while os.cpu_count() reports the whole machine;
@@ -236,6 +334,7 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=2048)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gym-level", action="store_true", help="skip the gym-level (HipRuntime.step) and rollout lines")
     ap.add_argument("--runtime-model", action="store_true",
                     help="perturb the robot constants so that the generic (run-time model) kernels are used")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -246,7 +345,7 @@ def main():
                     help="cut this rank's batch into that many contiguous shards, one handle and one stream each, advancing "
                          "independently (a shard waits for its own slowest wave only; DESIGN.md 7).  Results per environment "
                          "are those of the single batch, bit for bit.  Pays over long rollouts, once the shards have drifted out of "
-                         "phase (+7 % with 4 shards over 1000 steps, nothing over 20); default 1: one handle, one launch per env-step")
+                         "phase (+5 % with 4 shards over 1000 steps, a loss over 20); default 1: one handle, one launch per env-step")
     ap.add_argument("--rollout", type=int, default=0, metavar="K",
                     help="a SEPARATE measurement, never the headline: advance in open-loop rollouts of K env-steps per launch "
                          "(os2r_rollout: every wave steps its own environments K times, no device-wide barrier per env-step) instead "
@@ -445,6 +544,12 @@ def main():
                          "traffic_source": None if traffic is None else
                          "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " + str(traffic.get("source")) + "; not measured by this run)",
                          "algorithmic_bytes_per_launch": bytes_launch / S,
+                         "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(cfg, esz),
+                         # SURVEY 8(d)'s own count beside the builder's: the launch also moves the terminal
+                         # observation, counters and -- since round 4 -- the contact solver's state in and out
+                         "algorithmic_bytes_survey": survey_bytes_per_env_step(cfg, esz),
+                         "achieved_survey": survey_bytes_per_env_step(cfg, esz) * args.envs_per_gpu / per_launch_s / 1e9,
+                         "frac_survey": survey_bytes_per_env_step(cfg, esz) * args.envs_per_gpu / per_launch_s / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_per_launch": per_launch_s * 1e3,
                          "concurrent_launches": S,
                          "achieved_per_launch": bytes_launch / S / per_launch_s / 1e9,
@@ -472,6 +577,11 @@ def main():
         if spec and "roofline_valu" in out:
             # the specification's straightforward operation count (tests/diag/count_flops.py), for reference only
             out["roofline_valu"]["specification_flops_per_env_step"] = spec["flops_per_env_step"]
+        if world == 1 and S == 1 and args.rollout == 0 and not args.gather_obs and not args.no_gym_level and not getattr(args, "runtime_model", False):
+            # computed after the timed region, like cpu_baseline: the surface users call, and the open-loop rollout line
+            ck_g = cks[0] if cks else sim.checkpoint()
+            out["rollout"] = rollout_line(args, sim)
+            out["gym_level"] = gym_level(args, cfg, ck_g, value)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)

@@ -125,6 +125,9 @@ class HipRuntime:
         self._bad_pending = []    # step counters of the launches with device actions whose verdict is still out (oldest first)
         self._bad_seen = 0        # running count of clamped actions already reported
         self._bad_flag = None     # pinned word for the rare direct read (reset / close)
+        # step() lets the host run at most this many of its launches ahead of the device (2: the verdict on the actions of the
+        # step two calls ago is in before the next launch goes out; larger: later verdicts, a deeper queue)
+        self.max_inflight = 2
         cfg = getattr(self.task, "cfg", None) or SettingsConfig()
         self.model = dict(get_model(cfg.get_config(f"task_modes/{self.task.task_mode}/model")))
         self.pose_names = list(cfg.get_config("/resets").keys())
@@ -256,7 +259,7 @@ class HipRuntime:
                     count = int(m[0])
                     self._bad_pending.pop(0)
                     continue
-                if len(self._bad_pending) < 2:
+                if len(self._bad_pending) < max(1, int(self.max_inflight)):
                     break
                 if deadline is None:
                     deadline = time.perf_counter() + 5.0

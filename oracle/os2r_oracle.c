@@ -570,6 +570,8 @@ static int build_problem(const Os2rConfig* cfg, int contact_model, const EnvPara
 static int g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = 0, g_incons_once = 0, g_lag_box = 0;
 static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0;
 static double g_incons = 1e-4, g_stall = 0.0;
+static int g_prox_later = 0;             /* proximal iterations of an environment's second and later solves of an iteration (0: g_prox) */
+void orc_set_experimental_prox_later(int k) { g_prox_later = k; }
 static int g_trace = -1;                 /* ORC_TRACE_SOLVES=k in the environment: iterations with k or more solves are printed */
 static long long g_dbg_counter[4];       /* orc_debug_counter: [0] warm-started iterations, [1] of those with an active row that has no remembered impulse */
 static int g_dbg_on = 0;
@@ -593,7 +595,7 @@ long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = 
 #else
 enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = 0, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
-       g_trace = 0, g_dbg_on = 0 };
+       g_trace = 0, g_dbg_on = 0, g_prox_later = 0 };
 static const double g_incons = 1e-4, g_stall = 0.0;
 #endif
 
@@ -902,8 +904,9 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
 #endif
   /* ---- a small, well-conditioned free set: the dual solve ---- */
   {
-    int F[ORC_EXACT_SMALL], m = 0, small = g_small;
-    for (int r = 0; r < nr && small; ++r) if (fr[r]) { if (m < ORC_EXACT_SMALL) F[m++] = r; else small = 0; }
+    int F[ORC_EXACT_SMALL], m = 0, small = g_small;   /* (laboratory: g_small = 1: up to ORC_EXACT_SMALL rows; 2, 3: up to that many) */
+    const int small_max = g_small >= 2 && g_small < ORC_EXACT_SMALL ? g_small : ORC_EXACT_SMALL;
+    for (int r = 0; r < nr && small; ++r) if (fr[r]) { if (m < small_max) F[m++] = r; else small = 0; }
     if (small && m > 0) {
       double A[ORC_EXACT_SMALL][ORC_EXACT_SMALL], L[ORC_EXACT_SMALL][ORC_EXACT_SMALL] = {{0}}, D[ORC_EXACT_SMALL], mu_[ORC_EXACT_SMALL];
       for (int a = 0; a < m; ++a) for (int b = 0; b <= a; ++b) {
@@ -973,7 +976,8 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     }
   }
   double d[OS2R_MAX_DOF] = {0}, ds[OS2R_MAX_DOF] = {0};
-  for (int it = 0; it < ORC_EXACT_PROX; ++it) {
+  const int nprox = test_consistency && g_prox_later > 0 ? g_prox_later : ORC_EXACT_PROX;
+  for (int it = 0; it < nprox; ++it) {
     double z[OS2R_MAX_DOF];
     for (int i = 0; i < n; ++i) z[i] = h[i] + (it > 0 ? eps * d[i] : 0.0);
     for (int i = 0; i < n; ++i) for (int k = 0; k < i; ++k) z[i] -= Lf[i][k] * z[k];
@@ -987,7 +991,7 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
   double found = 0.0, left = 0.0;   /* squared residuals of the free rows before and after the step */
   for (int r = 0; r < nr; ++r) {
     if (!fr[r]) continue;
-    double s = ORC_EXACT_PROX * w[r];
+    double s = nprox * w[r];
     for (int k = 0; k < n; ++k) s += g[r][k] * ds[k];
     mu[r] = -s / eps;
     double wl = w[r];

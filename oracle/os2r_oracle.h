@@ -62,6 +62,7 @@ void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged frictio
 void orc_set_experimental_incons(double threshold);   /* studies: the inconsistent-free-set test's threshold (1e-4) */
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
 void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (3) */
+void orc_set_experimental_prox_later(int k);   /* studies: the same for an environment's second and later solves of an iteration (0: as the first) */
 void orc_set_experimental_stall(double factor);
 void orc_set_experimental_sweep_after_cut(int on);
 void orc_set_experimental_clamp_all(int on);

@@ -43,20 +43,27 @@ def surfaces(n, steps, preroll):
     rt = env.unwrapped
     sim = rt.sim
     sim.bench_steps(preroll)                   # the stationary regime (every robot on the ground), as bench.py
-    act = torch.rand(n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1
+    # fresh actions every step, as a policy would give them, but without a policy's kernels in the way: views of one tensor
+    # (holding ONE action for hundreds of steps is another workload: 513 us per step at 65 536 envs against 147)
+    acts = torch.rand(64, n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1
+    k = [0]
+
+    def act():
+        k[0] += 1
+        return acts[k[0] & 63]
 
     ms = sim.bench_steps(steps)
     out.append(("bare C-ABI loop, os2r_bench_steps (device RNG actions)", n * steps / (ms * 1e-3), ms / steps * 1e3, 0.0))
 
     o, r, d, t = (torch.empty(n, sim.D, dtype=sim.dtype, device=sim.device), torch.empty(n, dtype=sim.dtype, device=sim.device),
                   torch.empty(n, dtype=torch.uint8, device=sim.device), torch.empty(n, sim.D, dtype=sim.dtype, device=sim.device))
-    w, h = timed(lambda: sim.step_into(act, o, r, d, t), steps)
+    w, h = timed(lambda: sim.step_into(act(), o, r, d, t), steps)
     out.append(("HipSim.step_into (ctypes, caller's buffers)", n * steps / w, w / steps * 1e6, h / steps * 1e6))
-    w, h = timed(lambda: sim.step(act), steps)
+    w, h = timed(lambda: sim.step(act()), steps)
     out.append(("HipSim.step (ctypes, fresh output tensors)", n * steps / w, w / steps * 1e6, h / steps * 1e6))
-    w, h = timed(lambda: rt.step(act), steps)
+    w, h = timed(lambda: rt.step(act()), steps)
     out.append(("HipRuntime.step (device action tensor)", n * steps / w, w / steps * 1e6, h / steps * 1e6))
-    w, h = timed(lambda: env.step(act), steps)
+    w, h = timed(lambda: env.step(act()), steps)
     out.append(("randomizer wrapper .step", n * steps / w, w / steps * 1e6, h / steps * 1e6))
 
     def with_policy():
@@ -70,11 +77,11 @@ def surfaces(n, steps, preroll):
     venv = make_mp_envs(ENV_ID, n, 42, MonopodEnvRandomizer, max_episode_steps=100_000)
     venv.reset()
     venv.unwrapped.sim.bench_steps(preroll)
-    w, h = timed(lambda: venv.step(act), steps)
+    w, h = timed(lambda: venv.step(act()), steps)
     out.append(("HipVecEnv.step (make_mp_envs)", n * steps / w, w / steps * 1e6, h / steps * 1e6))
 
     def async_wait():
-        venv.step_async(act)
+        venv.step_async(act())
         venv.step_wait()
     w, h = timed(async_wait, steps)
     out.append(("HipVecEnv.step_async + step_wait", n * steps / w, w / steps * 1e6, h / steps * 1e6))

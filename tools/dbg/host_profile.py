@@ -23,6 +23,7 @@ env.seed(42)
 obs = env.reset()
 rt = env.unwrapped
 sim = rt.sim
+sim.bench_steps(1000)     # the stationary regime (every robot on the ground), as bench.py
 acts = torch.rand(64, n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1
 
 
@@ -40,15 +41,20 @@ def loop(fn, k=steps):
 
 o, r, d, t = (torch.empty(n, sim.D, dtype=sim.dtype, device=sim.device), torch.empty(n, dtype=sim.dtype, device=sim.device),
               torch.empty(n, dtype=torch.uint8, device=sim.device), torch.empty(n, sim.D, dtype=sim.dtype, device=sim.device))
+sets = [[torch.empty_like(x) for x in (o, r, d, t)] for _ in range(3)]      # rotating output sets: what fresh tensors amount to
 flag = torch.zeros(2, dtype=torch.int32).pin_memory()
 ev = torch.cuda.Event()
 print(f"# {n} environments, {steps} steps; columns: host us per call (enqueue returned) / wall us per call (device drained)")
 for label, fn in (
         ("sim.step_into(acts[i])", lambda i: sim.step_into(acts[i & 63], o, r, d, t)),
+        ("sim.step_into, three output sets in rotation", lambda i: sim.step_into(acts[i & 63], *sets[i % 3])),
+        ("sim.step_into again (one set)", lambda i: sim.step_into(acts[i & 63], o, r, d, t)),
         ("sim.step(acts[i]) (4 torch.empty)", lambda i: sim.step(acts[i & 63])),
         ("sim.step + action_violations_into (4-byte D2H copy)", lambda i: (sim.step(acts[i & 63]), sim.action_violations_into(flag[0:1], clear=False))),
         ("sim.step + event.record", lambda i: (sim.step(acts[i & 63]), ev.record())),
         ("sim.step + (flags != 0)", lambda i: sim.step(acts[i & 63])[2] != 0),
+        ("sim.step(want_mask=True)", lambda i: sim.step(acts[i & 63], want_mask=True)),
+        ("sim.bench_steps(1) (device RNG actions, scratch outputs)", lambda i: sim.bench_enqueue(1)),
         ("HipRuntime.step(acts[i])", lambda i: rt.step(acts[i & 63])),
         ("wrapper.step(acts[i])", lambda i: env.step(acts[i & 63]))):
     h, w = loop(fn)
