@@ -69,6 +69,10 @@ def build_config(args, rank, world, split=0, splits=1):
                             randomize_params=dr, max_episode_steps=100_000)
     n = args.envs_per_gpu
     base = rank * n
+    if getattr(args, "total_envs", None):
+        # rehearsal of uneven shards: the job's environments are cut into `world` contiguous ranges that differ by at most one
+        from gym_os2r_amd.distributed import shard_range
+        base, n = shard_range(args.total_envs, rank, world)
     if splits > 1:
         from gym_os2r_amd.distributed import shard_range
         off, n = shard_range(args.envs_per_gpu, split, splits)
@@ -141,8 +145,7 @@ def gym_level(args, cfg_bench, ck, value):
         sim.restore(ck)
     else:
         sim.bench_steps(max(args.preroll, 1))
-    K = max(10, min(args.steps, 300))
-    warm = 10
+    K, warm = 300, 30        # its own window whatever --steps is: over 20 steps the loop's start-up (first launches, allocator) is 10 % of it
     acts = torch.rand(K + warm, n, 2, dtype=sim.dtype, device=sim.device) * 2 - 1
     for k in range(warm):
         env.step(acts[k])
@@ -320,6 +323,9 @@ def main():
                          "stationary regime of the rollout whatever --warmup and --steps are (0: start at the reset)")
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--total-envs", type=int, default=None,
+                    help="rehearsals only: the whole job's environments, cut into one contiguous range per rank (ranges differ by at "
+                         "most one environment: the gather's uneven-shard path); default: --envs-per-gpu on every rank (weak scaling)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pgs-iters", type=int, default=None, help="cap on the phase-2 sweeps (default: abi.config_struct's: 14 with the exact finish -- 12 below five dof --, 20 without)")
@@ -400,7 +406,11 @@ def main():
     if use_dist and dist.get_world_size() != world:
         raise SystemExit(f"WORLD_SIZE={world} but the process group has {dist.get_world_size()} ranks")
     S = max(1, args.splits)
+    if args.total_envs and S > 1:
+        raise SystemExit("--total-envs (uneven ranges per rank) is a rehearsal of the gather path: not with --splits")
     cfg, model, spec = build_config(args, rank, world)
+    if args.total_envs:
+        args.envs_per_gpu = int(cfg.num_envs)         # this rank's range (the ranges differ by at most one environment)
     esz = 8 if args.dtype == "f64" else 4
     if S == 1:
         sims, streams = [HipSim(cfg, device=f"cuda:{local_rank}")], [None]
@@ -473,7 +483,8 @@ def main():
         # inside the loop, and a buffer is reused only after the gather that read it has finished (an event per buffer).
         from gym_os2r_amd.distributed import gather_to_rank0
         host = use_dist and args.backend == "gloo"    # gloo gathers host tensors: that rehearsal path stays synchronous
-        n, D = args.envs_per_gpu, sim.D
+        n, D = sim.N, sim.D
+        total_g = args.total_envs or args.envs_per_gpu * world
         bufs = [[torch.empty(n, D, dtype=sim.dtype, device=sim.device), torch.empty(n, dtype=sim.dtype, device=sim.device),
                  torch.empty(n, dtype=torch.uint8, device=sim.device)] for _ in range(2)]
         free = [None, None]                           # event: the gather that read buffer b has finished
@@ -490,12 +501,12 @@ def main():
             stepped = torch.cuda.Event()
             stepped.record(main)
             if host:
-                gathered = [gather_to_rank0(t.cpu(), n * world, key=nm) for t, nm in zip(bufs[b], ("obs", "reward", "done"))]
+                gathered = [gather_to_rank0(t.cpu(), total_g, key=nm) for t, nm in zip(bufs[b], ("obs", "reward", "done"))]
             else:
                 side.wait_event(stepped)
                 with torch.cuda.stream(side):
                     # (rank 0's [world * n, ...] outputs are allocated once, the collective writes into their slices)
-                    gathered = [gather_to_rank0(t, n * world, key=nm) for t, nm in zip(bufs[b], ("obs", "reward", "done"))]
+                    gathered = [gather_to_rank0(t, total_g, key=nm) for t, nm in zip(bufs[b], ("obs", "reward", "done"))]
                     free[b] = torch.cuda.Event()
                     free[b].record(side)
         ev1.record()
@@ -517,7 +528,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    total_envs = args.envs_per_gpu * world
+    total_envs = args.total_envs or args.envs_per_gpu * world
     value = total_envs * args.steps / elapsed
     if rank == 0:
         per_launch_s = kernel_ms * 1e-3 / args.steps     # (per env-step of the batch; a rollout launch makes --rollout of them)

@@ -1342,8 +1342,8 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     group(pgs_iters - it, false);
   };
   // ---- exact finish (fp64; kExact* above).  The rows of phase 2 in sweep order: ----
-  // f(slot, nz, g, target, lambda&, lo, hi, upper): row `slot` has the non-zeros g[0..nz] and an impulse in [lo, hi]
-  // (upper == false: no upper bound)
+  // f(slot, nz, g, target, rd, lambda&, lo, hi, upper): row `slot` has the non-zeros g[0..nz], the reciprocal rd of its squared norm
+  // and an impulse in [lo, hi] (upper == false: no upper bound)
   auto each_row = [&](auto first, auto&& f) {
     constexpr int kFirst = decltype(first)::value;
 #pragma unroll
@@ -1351,12 +1351,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
       const T lim = limfix[b];
-      f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(0), false);
-      f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true);
-      f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true);
+      f(3 * b + 0, b, Gr[b][0], erv[b], dn[b], ln[b], T(0), T(0), false);
+      f(3 * b + 1, b, Gr[b][1], T(0), dx[b], lx[b], -lim, lim, true);
+      f(3 * b + 2, b, Gr[b][2], T(0), dy[b], ly[b], -lim, lim, true);
     }
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true);
+    for (int j = 0; j < NQ; ++j) f(3 * NB + j, j, Lc[j], T(0), idj[j], lf[j], -fb[j], fb[j], true);
   };
   // The same, visiting only the rows whose bit is set in the wave-uniform mask U (bit 3b + t: row t of body b, bit 3 NB + j:
   // joint j) -- a body none of whose rows is in U, and the joint rows when none of them is, are passed over with ONE branch:
@@ -1370,14 +1370,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
       if (((U >> (3 * b)) & 7u) == 0u) continue;
       const T lim = limfix[b];
-      if ((U >> (3 * b + 0)) & 1u) f(3 * b + 0, b, Gr[b][0], erv[b], ln[b], T(0), T(0), false);
-      if ((U >> (3 * b + 1)) & 1u) f(3 * b + 1, b, Gr[b][1], T(0), lx[b], -lim, lim, true);
-      if ((U >> (3 * b + 2)) & 1u) f(3 * b + 2, b, Gr[b][2], T(0), ly[b], -lim, lim, true);
+      if ((U >> (3 * b + 0)) & 1u) f(3 * b + 0, b, Gr[b][0], erv[b], dn[b], ln[b], T(0), T(0), false);
+      if ((U >> (3 * b + 1)) & 1u) f(3 * b + 1, b, Gr[b][1], T(0), dx[b], lx[b], -lim, lim, true);
+      if ((U >> (3 * b + 2)) & 1u) f(3 * b + 2, b, Gr[b][2], T(0), dy[b], ly[b], -lim, lim, true);
     }
     if (((U >> (3 * NB)) & ((1u << NQ) - 1u)) != 0u) {
 #pragma unroll
       for (int j = 0; j < NQ; ++j)
-        if ((U >> (3 * NB + j)) & 1u) f(3 * NB + j, j, Lc[j], T(0), lf[j], -fb[j], fb[j], true);
+        if ((U >> (3 * NB + j)) & 1u) f(3 * NB + j, j, Lc[j], T(0), idj[j], lf[j], -fb[j], fb[j], true);
     }
   };
   // One exact solve of the rows strictly inside their box, every other row held at its bound.  Returns whether a
@@ -1410,18 +1410,21 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // which rows are free for some lane at work here (two or three of the 64, typically, with two free rows each): found once
     // per solve -- the impulses do not move before the last pass -- branch-free, kept as one scalar bit mask
     unsigned U = 0u;
-    each_row(first, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
+    each_row(first, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
       U |= __ballot(is_free(l, lo, hi, upper)) != 0ull ? (1u << slot) : 0u;
     });
     // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
     // A row that is free for none of the lanes at work here -- typically two or three of the 64 -- adds exact zeros to S
     // and h, has mu = 0 and keeps its impulse: the wave skips it in every pass (void for every lane, so a lane's result
     // does not depend on its company).
-    each_row_in(first, U, [&](int, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
+    each_row_in(first, U, [&](int, int nz, const T (&g)[NQ], T target, T rd, T& l, T lo, T hi, bool upper) {
       const bool fr = is_free(l, lo, hi, upper);
       // the row's weight as a number the optimiser cannot see through: it would turn the products below back into
-      // selects of every entry (two v_cndmask per double) or into a branch around the row
-      const T f = opaque(fr ? T(1) : T(0));
+      // selects of every entry (two v_cndmask per double) or into a branch around the row.  A free row weighs 1 / |g|^2 (round 5):
+      // rows of very different mobility -- the tangential row along the boom has a thousandth of the others' squared norm -- would
+      // otherwise put a direction of S below the regularisation, where the proximal iterations converge at 0.87 per iteration,
+      // the consistency test takes the set for inconsistent and the solves zigzag between two bounds of that row
+      const T f = opaque(fr ? rd : T(0));
       T w = -target;
 #pragma unroll
       for (int k = 0; k < NQ; ++k)
@@ -1504,9 +1507,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // (the variant that also measures the residuals before and after the step runs when a lane of the wave asks for it)
     T found = T(0), left = T(0);
     auto pass2 = [&](auto measure_) {
-      each_row_in(first, U, [&](int slot, int nz, const T (&g)[NQ], T target, T& l, T lo, T hi, bool upper) {
+      each_row_in(first, U, [&](int slot, int nz, const T (&g)[NQ], T target, T rd, T& l, T lo, T hi, bool upper) {
         const bool fr = is_free(l, lo, hi, upper);
-        const T f = opaque(fr ? ieps : T(0));
+        const T f = opaque(fr ? opaque(ieps * rd) : T(0));
         T w = -target;
 #pragma unroll
         for (int k = 0; k < NQ; ++k)
@@ -1540,7 +1543,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     T alpha = T(1);
     if (__ballot(cut | incons) != 0ull) {
       T a = incons ? T(kExactNoBound) : T(1);
-      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
+      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
         const T m = mu_get(slot);
         const bool up = m > T(0);
         const bool bounded = (m < T(0)) | (upper ? up : false);
@@ -1558,7 +1561,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
 #pragma unroll
     for (int i = 0; i < NQ; ++i) y[i] = fma_t(alpha, d[i], y[i]);
     if (__ballot(cut) != 0ull) {
-      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
+      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
         const T m = mu_get(slot);
         T nl = fma_t(alpha, m, l);
         const bool at_hi = cut & (upper ? ((m > T(0)) & ((hi - nl) <= T(kExactSnap) * (hi - l))) : false);
@@ -1571,7 +1574,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
       });
     } else {
       // (a row of U that is not free for this lane has the multiplier 0 and sits inside its box)
-      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T& l, T lo, T hi, bool upper) {
+      each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
         T nl = l + mu_get(slot);
         nl = fmax_t(nl, lo);
         if (upper) nl = fmin_t(nl, hi);

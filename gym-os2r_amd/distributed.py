@@ -68,8 +68,10 @@ class Rank0Gather:
         import torch
         return torch.empty((rows,) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
 
-    def __call__(self, tensor, key="x", out=None):
-        """-> the gathered [total_envs, ...] tensor on rank ``dst`` (the same storage every call unless ``out`` is given), None elsewhere."""
+    def __call__(self, tensor, key=None, out=None):
+        """-> the gathered [total_envs, ...] tensor on rank ``dst``, None elsewhere.  With a ``key`` the output is the gatherer's own
+        buffer for that key (the same storage every call: two call sites must not share a key); without one, and without ``out``,
+        a fresh tensor per call."""
         import torch.distributed as dist
         if tensor.shape[0] != self.counts[self.rank]:
             raise ValueError(f"rank {self.rank} owns {self.counts[self.rank]} environments, got {tensor.shape[0]} rows")
@@ -77,9 +79,11 @@ class Rank0Gather:
         sig = (key, tuple(tensor.shape[1:]), tensor.dtype, tensor.device)
         on_dst = self.rank == self.dst
         if on_dst and out is None:
-            out = self._out.get(sig)
+            out = self._out.get(sig) if key is not None else None
             if out is None:
-                out = self._out[sig] = self._like(tensor, self.total)
+                out = self._like(tensor, self.total)
+                if key is not None:
+                    self._out[sig] = out
         if self.even:
             views = [out[o:o + c] for o, c in zip(self.offsets, self.counts)] if on_dst else None
             dist.gather(tensor, views, dst=self.dst)
@@ -106,15 +110,21 @@ class Rank0Gather:
 _gatherers = {}
 
 
-def gather_to_rank0(tensor, total_envs: int, dst: int = 0, key="x", out=None):
+def gather_to_rank0(tensor, total_envs: int, dst: int = 0, key=None, out=None):
     """Per-rank [n_r, ...] tensors -> one [total_envs, ...] tensor on rank ``dst`` in global env order (None elsewhere):
-    ``Rank0Gather`` with one cached instance per (total_envs, dst).  The result on rank ``dst`` is the gatherer's own
-    buffer for ``key`` -- overwritten by the next gather with the same key, shape and dtype -- unless ``out`` is given.
-    Without a process group the tensor is returned as it is."""
+    ``Rank0Gather`` with one cached instance per (process group, total_envs, dst) -- a group that is destroyed and initialised
+    again, with another rank or backend, gets a new one.  With a ``key`` the result on rank ``dst`` is the gatherer's own buffer
+    for that key -- overwritten by the next gather with the same key, shape and dtype --; without one (and without ``out``) it is
+    a fresh tensor.  Without a process group the tensor is returned as it is."""
     import torch.distributed as dist
     if not dist.is_initialized():
         return tensor
-    g = _gatherers.get((int(total_envs), int(dst), dist.get_world_size()))
+    pg = dist.distributed_c10d._get_default_group()
+    ident = (id(pg), dist.get_backend(), dist.get_rank(), dist.get_world_size(), int(total_envs), int(dst))
+    g = _gatherers.get(ident)
     if g is None:
-        g = _gatherers[(int(total_envs), int(dst), dist.get_world_size())] = Rank0Gather(total_envs, dst)
+        for k in [k for k in _gatherers if k[0] != id(pg)]:      # buffers of groups that are gone
+            del _gatherers[k]
+        g = _gatherers[ident] = Rank0Gather(total_envs, dst)
+        g._pg = pg                                     # (keeps the group object alive, so its id cannot be reused while cached)
     return g(tensor, key=key, out=out)

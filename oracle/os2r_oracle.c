@@ -561,15 +561,20 @@ static int build_problem(const Os2rConfig* cfg, int contact_model, const EnvPara
  * contact are minimised over exactly as a block (enumeration of the active sets of the 3-variable box QP, first
  * assignment that meets the optimality conditions) instead of row by row.  Measures what an exact per-contact
  * block would buy in closed loop before anything of the kind is built for the GPU. */
+#define ORC_EXACT_SMALL_SPEC 0   /* (laboratory: free sets of at most that many rows are solved in the dual; the specification: none, see below) */
 /* ---- the laboratory (ORC_EXPERIMENTS) ----
  * The solver studies of rounds 3-5 (docs/studies/) run on switches that change what the solver below does.  They exist ONLY in
  * the laboratory build (make lab -> liboracle_lab.so, -DORC_EXPERIMENTS; used by tests/diag/ and the studies): in the checker
  * (libos2r_oracle.so: what tests/, smoke() and bench.py's cpu_baseline load) every one of them is the compile-time constant of
  * the specification, no setter is exported and the experimental branches are dead code. */
 #ifdef ORC_EXPERIMENTS
-static int g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = 0, g_incons_once = 0, g_lag_box = 0;
+static int g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0;
 static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0;
 static double g_incons = 1e-4, g_stall = 0.0;
+static int g_pivot = 0;                  /* 1: an inconsistent-set step that would pin a row it has pinned before in this iteration ends phase 2 instead (round 5) */
+void orc_set_experimental_pivot(int on) { g_pivot = on; }
+static int g_equil = 1;                  /* the regularised solve takes every free row with the weight 1 / |g_r|^2 (the specification since round 5; 0: round 4) */
+void orc_set_experimental_equil(int on) { g_equil = on; }
 static int g_prox_later = 0;             /* proximal iterations of an environment's second and later solves of an iteration (0: g_prox) */
 void orc_set_experimental_prox_later(int k) { g_prox_later = k; }
 static int g_trace = -1;                 /* ORC_TRACE_SOLVES=k in the environment: iterations with k or more solves are printed */
@@ -593,9 +598,9 @@ void orc_set_experimental_warm(int mode, int first) {
 }
 long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
 #else
-enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = 0, g_incons_once = 0, g_lag_box = 0,
+enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
-       g_trace = 0, g_dbg_on = 0, g_prox_later = 0 };
+       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1 };
 static const double g_incons = 1e-4, g_stall = 0.0;
 #endif
 
@@ -770,9 +775,15 @@ static int block_update_pair(int n, Row* rows, int r0, double* v, double* moved)
  * solves its FREE rows (strictly inside their box) exactly, all other rows held at their bounds:
  *     whitened coordinates  Minv = Lc Lc^T,  y = Lc^-1 v,  g_r = Lc^T J_r   (so J_r v = g_r . y,  Minv J_r^T = Lc g_r)
  *     minimum-norm change d of y with  g_r . (y + d) = t_r  for r in F:
- *         (S + eps I) d = -sum_F g_r w_r,   S = sum_F g_r g_r^T (5 x 5, whatever |F| is),  w_r = g_r . y - t_r,
- *         eps = ORC_EXACT_EPS * trace S,  ORC_EXACT_PROX proximal iterations (d_k from h + eps d_{k-1}) sharpen it;
- *         the impulses of the free rows follow from the residuals:  mu_r = -(K w_r + g_r . sum_k d_k) / eps
+ *         (S + eps I) d = -sum_F c_r g_r w_r,   S = sum_F c_r g_r g_r^T (5 x 5, whatever |F| is),  w_r = g_r . y - t_r,
+ *         c_r = 1 / |g_r|^2: every free row is taken at unit length (round 5.  Rows differ in mobility by three orders of
+ *         magnitude -- a contact on a leg link can hardly move ALONG the boom: |g|^2 = 5e-3 against 2 .. 9 for the other two rows
+ *         of the contact -- and unweighted such a row put a direction of S at 1.5e-7 of its trace, below the regularisation:
+ *         the proximal iterations converge at 0.87 per iteration there, the consistency test below takes the set for
+ *         inconsistent and the solves zigzag between the two bounds of that row until they are spent, leaving up to 3 % of the
+ *         velocity wrong: docs/studies/round5_solver.md),
+ *         eps = ORC_EXACT_EPS * trace S (= ORC_EXACT_EPS * |F|),  ORC_EXACT_PROX proximal iterations (d_k from h + eps d_{k-1}) sharpen it;
+ *         the impulses of the free rows follow from the residuals:  mu_r = -c_r (K w_r + g_r . sum_k d_k) / eps
  *     (the regularisation keeps d in the range of the free rows, and 8 sticking rows in 5 dof are no special case).
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set
  * on its bound and the solve repeated with the smaller free set); after a full step one ordinary sweep re-tests every
@@ -790,17 +801,18 @@ static int block_update_pair(int n, Row* rows, int r0, double* v, double* moved)
  * ORC_EXACT_INCONS of what it found (squared norms), it goes on in the direction of its multipliers -- past the full
  * step -- to the first bound it meets, sets that row on it and solves again, as after a cut. */
 #define ORC_EXACT_INCONS g_incons
-/* EXPERIMENT (oracle only, off by default; docs/studies/round4_solver.md): small free sets solved in the dual.  In the
- * regimes the stepper lives in, an environment that needs a solve has two free rows -- the normal and one tangential row
- * of a sticking-sliding contact, or the normals of two contacts -- seldom three and hardly ever more (joints slide: their
- * friction rows sit on their bounds).  With the switch on, a free set of at most ORC_EXACT_SMALL rows is solved in the
- * DUAL: A mu = -w with A = G_F G_F^T (m x m, L D L^T in sweep order, no pivoting), the impulses move by mu and the velocity
- * by Minv J_F^T mu -- the same equality-constrained minimum as the regularised 5 x 5 solve below -- with the same cut at
- * the first bound; a set whose rows are (nearly) dependent -- a pivot below ORC_EXACT_SMALL_PIVOT of its diagonal entry --
- * or larger takes the regularised solve.  It serves 99.7 % of the solves of the bench workload and passes every exactness
- * test; on the GPU its gather / scatter through per-lane LDS slots cost as much as the regularised solve it replaces
- * (a wave that owns its SIMD pays per instruction, branch and LDS round trip, not per flop), so the kernels do not have
- * it and the specification stays with the one solve. */
+/* EXPERIMENT (laboratory only, orc_set_experimental_small(1 .. 3); docs/studies/round4_solver.md, round5_solver.md): small free sets
+ * solved in the DUAL.  In the regimes the stepper lives in, an environment that needs a solve has two free rows -- the normal and
+ * one tangential row of a contact that sticks along one world axis and slides along the other (77 % of the solves of C4, 89 % of
+ * C3), or the normals of two contacts (14 %) -- or one (4 %), seldom three and hardly ever more.  With the switch on, a free set of
+ * at most that many rows is solved as A mu = -w with A = G_F G_F^T (L D L^T in sweep order, no pivoting): the impulses move by mu
+ * and the velocity by Minv J_F^T mu -- the same equality-constrained minimum as the regularised 5 x 5 solve below -- with the same
+ * cut at the first bound; a set whose rows are (nearly) dependent -- a pivot below ORC_EXACT_SMALL_PIVOT of its diagonal entry -- or
+ * larger takes the regularised solve.  It passes every exactness test.  Built into the kernels twice and measured slower both
+ * times: round 4 gathered the rows through per-lane LDS slots; round 5 gathered a lane's two rows with selects while the rows of the
+ * wave's free-row mask go by (no LDS) -- as many instructions as the regularised solve it replaces, because that solve already
+ * visits only the rows that are free for some lane at work (three or four), and a longer tail (profiles/r05_ab/).  The
+ * specification stays with the one solve. */
 #define ORC_EXACT_SMALL 3
 #define ORC_EXACT_SMALL_PIVOT 1e-8
 static _Thread_local int tl_last_small = 0;   /* diagnostics: dual solves among the solves of the last iteration */
@@ -852,6 +864,8 @@ static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu
 }
 
 static _Thread_local int tl_incons_steps = 0;   /* steps to the first bound of an inconsistent free set taken so far in this iteration */
+static int warm_slot(const Row* rows, int r);
+static _Thread_local unsigned tl_incons_pinned = 0u;   /* rows (by warm slot) that such steps have set on a bound in this iteration */
 #ifdef ORC_EXPERIMENTS
 /* laboratory diagnostics (orc_debug_free_set_hist): the shape of the free set of every exact solve, by the solve's index within its
  * physics iteration (0 .. 15) -- class 0: the normal and ONE tangential row of one contact, 1: two normals, 2: one row, 3: the three
@@ -883,7 +897,7 @@ static void note_free_set(const Row* rows, int nr, const int* fr) {
 #endif
 /* one exact solve of the free rows; returns 1 if the step was cut short by a bound */
 static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int test_consistency) {
-  double g[3 * OS2R_MAX_DOF + OS2R_MAX_DOF][OS2R_MAX_DOF], w[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
+  double g[3 * OS2R_MAX_DOF + OS2R_MAX_DOF][OS2R_MAX_DOF], w[3 * OS2R_MAX_DOF + OS2R_MAX_DOF], wgt[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   int fr[3 * OS2R_MAX_DOF + OS2R_MAX_DOF];
   double S[OS2R_MAX_DOF][OS2R_MAX_DOF] = {{0}}, h[OS2R_MAX_DOF] = {0};
   double tr = 0.0;
@@ -895,7 +909,8 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     for (int k = 0; k < n; ++k) { double s = 0; for (int j = k; j < n; ++j) s += R->J[j] * lc[j * n + k]; g[r][k] = s; }
     double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];
     w[r] = res;
-    for (int i = 0; i < n; ++i) { h[i] -= g[r][i] * res; for (int j = 0; j < n; ++j) S[i][j] += g[r][i] * g[r][j]; }
+    wgt[r] = g_equil ? 1.0 / R->d : 1.0;
+    for (int i = 0; i < n; ++i) { h[i] -= wgt[r] * g[r][i] * res; for (int j = 0; j < n; ++j) S[i][j] += wgt[r] * g[r][i] * g[r][j]; }
   }
   for (int i = 0; i < n; ++i) tr += S[i][i];
   if (!(tr > 0.0)) return 0;                       /* no free row: nothing to solve */
@@ -904,8 +919,8 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
 #endif
   /* ---- a small, well-conditioned free set: the dual solve ---- */
   {
-    int F[ORC_EXACT_SMALL], m = 0, small = g_small;   /* (laboratory: g_small = 1: up to ORC_EXACT_SMALL rows; 2, 3: up to that many) */
-    const int small_max = g_small >= 2 && g_small < ORC_EXACT_SMALL ? g_small : ORC_EXACT_SMALL;
+    int F[ORC_EXACT_SMALL], m = 0, small = g_small;   /* (laboratory: g_small = 0: off, 1 .. 3: sets of up to that many rows) */
+    const int small_max = g_small < ORC_EXACT_SMALL ? g_small : ORC_EXACT_SMALL;
     for (int r = 0; r < nr && small; ++r) if (fr[r]) { if (m < small_max) F[m++] = r; else small = 0; }
     if (small && m > 0) {
       double A[ORC_EXACT_SMALL][ORC_EXACT_SMALL], L[ORC_EXACT_SMALL][ORC_EXACT_SMALL] = {{0}}, D[ORC_EXACT_SMALL], mu_[ORC_EXACT_SMALL];
@@ -993,7 +1008,7 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     if (!fr[r]) continue;
     double s = nprox * w[r];
     for (int k = 0; k < n; ++k) s += g[r][k] * ds[k];
-    mu[r] = -s / eps;
+    mu[r] = -wgt[r] * s / eps;
     double wl = w[r];
     for (int k = 0; k < n; ++k) wl += g[r][k] * d[k];
     found += w[r] * w[r]; left += wl * wl;
@@ -1006,15 +1021,24 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
    * cycling of docs/studies/round4_solver.md is a second, third, ... such step undoing the first) */
   const int on = test_consistency && !cut && left > ORC_EXACT_INCONS * found && (g_incons_once <= 0 || tl_incons_steps < g_incons_once);
   double alpha = on ? INFINITY : 1.0;
+  int first_hit = -1;
   if (cut || on)
     for (int r = 0; r < nr; ++r) {
       if (!fr[r] || mu[r] == 0.0) continue;
       double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
       if (mu[r] > 0.0 && !isfinite(hi)) continue;
       const double lim = ((mu[r] > 0.0 ? hi : lo) - rows[r].lambda) / mu[r];
-      if (lim < alpha) alpha = lim;
+      if (lim < alpha) { alpha = lim; first_hit = r; }
     }
   if (on) { if (isfinite(alpha)) cut = 1; else alpha = 1.0; }
+  if (g_pivot && on && cut && first_hit >= 0) {
+    /* the step of an inconsistent set ends on row first_hit.  If such a step has set that row on a bound before in this
+     * iteration -- the re-test sweep released it in between -- the environment is cycling (docs/studies/round5_solver.md): it keeps
+     * the state the last sweep left and ends phase 2 */
+    const unsigned bit = 1u << warm_slot(rows, first_hit);
+    if (tl_incons_pinned & bit) return 2;
+    tl_incons_pinned |= bit;
+  }
   if (on && cut) tl_incons_steps += 1;
   if (g_trace > 0) {
     int nviol = 0;
@@ -1084,6 +1108,13 @@ static int warm_slot(const Row* rows, int r) {
 }
 
 static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, double tol, int exact, const double* minv, double* v) {
+#ifdef ORC_EXPERIMENTS
+  /* laboratory: ORC_DUMP_SOLVES=<file> with ORC_TRACE_SOLVES=k appends every problem that took k or more solves (its rows as they
+   * come in, the unconstrained velocity, Minv) as one JSON object per line (tests/diag/r5_dump_replay.py) */
+  Row rows_in[3 * OS2R_MAX_DOF + OS2R_MAX_DOF]; double v_in[OS2R_MAX_DOF];
+  const int dumping = g_trace > 0 && nr <= 3 * OS2R_MAX_DOF + OS2R_MAX_DOF;
+  if (dumping) { memcpy(rows_in, rows, (size_t)nr * sizeof(Row)); memcpy(v_in, v, (size_t)n * sizeof(double)); }
+#endif
   int order[ORC_MAX_ROWS];
   for (int r = 0; r < nr; ++r) order[r] = r;
   if (g_row_order != 0)
@@ -1141,7 +1172,8 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
       }
     int solves = 0, rounds = 0, solves_at_measure = 0, incons_at_measure = 0;
-    if (phase == 1) tl_incons_steps = 0;
+    if (phase == 1) { tl_incons_steps = 0; tl_incons_pinned = 0u; }
+    int cycling = 0;
     double e_prev = -1.0;
     if (phase == 1) { tl_last_sweeps = 0; tl_last_solves = 0; tl_last_small = 0; tl_trace_len = 0; }
 #ifdef ORC_EXPERIMENTS
@@ -1157,7 +1189,9 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
           tl_solve_index = solves;
 #endif
           blocked = exact_step(n, rows, nr, lc, v, solves > 0); ++solves; if (g_sweep_after_cut) break;
+          if (blocked == 2) { cycling = 1; break; }
         }
+        if (cycling) { tl_last_solves = solves; break; }
         tl_last_solves = solves;
         ++rounds;
       }
@@ -1192,6 +1226,25 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       }
     }
     if (phase == 1 && g_trace > 0 && solves >= g_trace) { tl_trace[tl_trace_len] = 0; fprintf(stderr, "solves %d sweeps %d:%s\n", solves, tl_last_sweeps, tl_trace); }
+#ifdef ORC_EXPERIMENTS
+    if (phase == 1 && dumping && solves >= g_trace && getenv("ORC_DUMP_SOLVES")) {
+      char buf[16384]; int o = 0;
+      o += snprintf(buf + o, sizeof(buf) - o, "{\"n\": %d, \"nr\": %d, \"solves\": %d, \"vstar\": [", n, nr, solves);
+      for (int i = 0; i < n; ++i) o += snprintf(buf + o, sizeof(buf) - o, "%s%.17g", i ? ", " : "", v_in[i]);
+      o += snprintf(buf + o, sizeof(buf) - o, "], \"minv\": [");
+      for (int i = 0; i < n * n; ++i) o += snprintf(buf + o, sizeof(buf) - o, "%s%.17g", i ? ", " : "", minv[i]);
+      o += snprintf(buf + o, sizeof(buf) - o, "], \"rows\": [");
+      for (int r = 0; r < nr; ++r) {
+        o += snprintf(buf + o, sizeof(buf) - o, "%s{\"kind\": %d, \"body\": %d, \"normal_row\": %d, \"target\": %.17g, \"bound\": %.17g, \"J\": [", r ? ", " : "",
+                      rows_in[r].kind, rows_in[r].body, rows_in[r].normal_row, rows_in[r].target, rows_in[r].bound);
+        for (int i = 0; i < n; ++i) o += snprintf(buf + o, sizeof(buf) - o, "%s%.17g", i ? ", " : "", rows_in[r].J[i]);
+        o += snprintf(buf + o, sizeof(buf) - o, "]}");
+      }
+      o += snprintf(buf + o, sizeof(buf) - o, "]}\n");
+      FILE* f = fopen(getenv("ORC_DUMP_SOLVES"), "a");
+      if (f) { fwrite(buf, 1, (size_t)o, f); fclose(f); }
+    }
+#endif
     if (phase == 1 && exact > 0 && g_warm && nr <= ORC_WARM_ROWS) {
       warm_forget(tl_warm);
       for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0) tl_warm[warm_slot(rows, r)] = rows[r].lambda;
@@ -1417,7 +1470,6 @@ int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves) {
   if (solves) memcpy(solves, s->solver_counts + n, n);
   return 0;
 }
-#ifdef ORC_EXPERIMENTS
 /* (recording on:) how many of those solves were dual solves of a small free set */
 int orc_get_small_solve_counts(OrcSim* s, int8_t* small) {
   const size_t n = (size_t)s->cfg.substeps * s->N;
@@ -1425,7 +1477,6 @@ int orc_get_small_solve_counts(OrcSim* s, int8_t* small) {
   memcpy(small, s->solver_counts + 2 * n, n);
   return 0;
 }
-#endif
 
 static void observe_env(const OrcSim* s, int64_t e, double* obs) {
   const int n = s->cfg.model.nq; const int64_t N = s->N;

@@ -49,10 +49,10 @@ void orc_destroy(OrcSim* s);
 void orc_set_threads(OrcSim* s, int n);
 void orc_set_contact_model(OrcSim* s, int model);
 int orc_get_solver_counts(OrcSim* s, int8_t* sweeps, int8_t* solves);   /* diagnostics: [substeps][N] each, of the last step; the first call switches recording on */
+int orc_get_small_solve_counts(OrcSim* s, int8_t* small);               /* of those solves: the dual solves of small free sets */
 #ifdef ORC_EXPERIMENTS
 /* The laboratory build only (make lab -> liboracle_lab.so; tests/diag/ and the studies under docs/studies/): switches that change
  * what the solver does.  The checker library (libos2r_oracle.so) has none of them: there they are the specification's constants. */
-int orc_get_small_solve_counts(OrcSim* s, int8_t* small);               /* of those solves: the dual solves of small free sets */
 void orc_set_experimental_block_solve(int on);   /* oracle-only experiments, see os2r_oracle.c */
 void orc_set_experimental_row_order(int order);
 void orc_set_experimental_rounds(int max_rounds, int stop_at_cap);
@@ -62,13 +62,15 @@ void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged frictio
 void orc_set_experimental_incons(double threshold);   /* studies: the inconsistent-free-set test's threshold (1e-4) */
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
 void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (3) */
+void orc_set_experimental_equil(int on);   /* studies: 1 (the specification since round 5) -- the regularised solve weighs every free row with 1 / |g_r|^2; 0: round 4 */
+void orc_set_experimental_pivot(int on);   /* studies (round 5): 1 -- an inconsistent-set step that would pin a row it pinned before in this iteration ends phase 2 */
 void orc_set_experimental_prox_later(int k);   /* studies: the same for an environment's second and later solves of an iteration (0: as the first) */
 void orc_set_experimental_stall(double factor);
 void orc_set_experimental_sweep_after_cut(int on);
 void orc_set_experimental_clamp_all(int on);
 void orc_set_experimental_block_kind(int kind);   /* 0: enumeration of the block's active sets, 1: Gauss-Seidel pass + one exact solve of the rows left free */
 void orc_set_experimental_warm(int mode, int first);  /* studies: 1 the specification, 0 no warm start, 2 round 3 (forgotten between env-steps); K sweeps before the first check */
-void orc_set_experimental_small(int on);   /* studies: 1 switches the dual solve of small free sets on (off: every solve is the regularised one) */
+void orc_set_experimental_small(int max_rows);   /* studies: the dual solve serves free sets of up to that many rows (0: every solve is the regularised one -- the specification; at most 3) */
 #endif
 int orc_get_solver_state(OrcSim* s, double* lam, uint32_t* flags);   /* layout of os2r_get_solver_state (include/os2r.h) */
 int orc_set_solver_state(OrcSim* s, const double* lam, const uint32_t* flags);

@@ -105,13 +105,17 @@ def pgs_two_phase(p, normal_iters=3, iters=20, tol=1e-24, group=4):
     return v, lam, box, ran
 
 
-def pgs_exact_finish(p, normal_iters=3, iters=None, tol=1e-24, exact=12, first=None, eps_rel=1e-6, prox=3, snap=1e-12, incons=1e-4):
+def pgs_exact_finish(p, normal_iters=3, iters=None, tol=1e-24, exact=12, first=None, eps_rel=1e-6, prox=3, snap=1e-12, incons=1e-4,
+                     small=0, small_pivot=1e-8, equil=True):
     """The specification's solver with the exact finish, restated on the
     exported rows: phase 1 as in pgs_two_phase; phase 2 = `first` sweeps, then -- while the last sweep moved more than
     `tol` -- exact solves of the free rows (repeated while a bound cuts the step short, `exact` at most) each followed
     by one sweep; `iters` bounds the sweeps.  From the second solve of the call on, a solve that is not cut and leaves
     more than `incons` of the squared residual it found on its free rows (an inconsistent free set) goes on along its
-    multipliers to the first bound and counts as cut.  -> (v, lam, box, sweeps of phase 2, exact solves)"""
+    multipliers to the first bound and counts as cut.  `small` > 0 (studies; not the specification): a free set of at most that
+    many rows (two at most here) is solved in the dual, (G_F G_F^T) mu = -w, unless its second pivot is below `small_pivot`.
+    `equil` (the specification since round 5): every free row enters the regularised solve with the weight 1 / |g_r|^2.
+    -> (v, lam, box, sweeps of phase 2, exact solves)"""
     J, minv, t, kind, nrow = p["J"], p["minv"], p["target"], p["kind"], p["normal_row"]
     nr, n = J.shape
     if first is None:
@@ -154,21 +158,43 @@ def pgs_exact_finish(p, normal_iters=3, iters=None, tol=1e-24, exact=12, first=N
             while blocked and solves < exact:
                 solves += 1
                 F = (d > 0) & (lam > lo) & (lam < hi)
-                S = G[F].T @ G[F]
+                wgt = 1.0 / d[F] if equil else np.ones(int(F.sum()))     # equil: every free row is taken with weight 1 / |g_r|^2
+                S = (G[F] * wgt[:, None]).T @ G[F]
                 tr = np.trace(S)
                 if not tr > 0:
                     blocked = False
                     break
                 eps = eps_rel * tr
                 w = G[F] @ y - t[F]
-                h = -G[F].T @ w
+                A2 = G[F] @ G[F].T
+                dual = 0 < F.sum() <= small and (F.sum() == 1 or A2[1, 1] - A2[0, 1] ** 2 / A2[0, 0] > small_pivot * A2[1, 1])
+                if dual:
+                    mu = np.linalg.solve(A2, -w)
+                    full = lam[F] + mu
+                    blocked = bool(((full < lo[F]) | (full > hi[F])).any())
+                    alpha = 1.0
+                    if blocked:
+                        with np.errstate(divide="ignore", invalid="ignore"):
+                            lim = np.where(mu > 0, (hi[F] - lam[F]) / mu, np.where(mu < 0, (lo[F] - lam[F]) / mu, np.inf))
+                        alpha = min(1.0, lim.min())
+                    y += alpha * (G[F].T @ mu)
+                    for j, m in zip(np.nonzero(F)[0], mu):
+                        nl = lam[j] + alpha * m
+                        if blocked:
+                            if m > 0 and np.isfinite(hi[j]) and hi[j] - nl <= snap * (hi[j] - lam[j]):
+                                nl = hi[j]
+                            if m < 0 and nl - lo[j] <= snap * (lam[j] - lo[j]):
+                                nl = lo[j]
+                        lam[j] = min(max(nl, lo[j]), hi[j])
+                    continue
+                h = -G[F].T @ (wgt * w)
                 A = S + eps * np.eye(n)
                 dk = np.zeros(n)
                 ds = np.zeros(n)
                 for k in range(prox):
                     dk = np.linalg.solve(A, h + eps * dk)
                     ds += dk
-                mu = -(prox * w + G[F] @ ds) / eps
+                mu = -wgt * (prox * w + G[F] @ ds) / eps
                 full = lam[F] + mu
                 blocked = bool(((full < lo[F]) | (full > hi[F])).any())      # the full step leaves a box: cut it
                 left = w + G[F] @ dk

@@ -52,6 +52,11 @@ def _worker(rank, world, port, total, q):
     if rank == 0:
         assert again.data_ptr() == g_obs.data_ptr() and float(again[0, 0]) == 0.0 and float(again[-1, 0]) == float(world - 1)
     g_obs = gather_to_rank0(torch.from_numpy(obs), total, key="obs")
+    # without a key every call returns its own tensor: two anonymous call sites cannot alias each other
+    anon1 = gather_to_rank0(torch.from_numpy(obs), total)
+    anon2 = gather_to_rank0(torch.from_numpy(obs) * 0, total)
+    if rank == 0:
+        assert anon1.data_ptr() != anon2.data_ptr() and torch.equal(anon1, g_obs) and float(anon2.abs().max()) == 0.0
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)         # max-over-ranks timing reduction used by bench.py
     assert float(t) == world
@@ -63,18 +68,19 @@ def _worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total,world,port", [(37, 2, 29533), (36, 2, 29535), (9, 1, 29537)])
+@pytest.mark.parametrize("total,world,port", [(37, 2, 29533), (36, 2, 29535), (9, 1, 29537), (61, 8, 29539), (64, 8, 29551)])
 def test_two_rank_shards_reproduce_the_single_handle_run(oracle, total, world, port):
     """uneven shards (19 + 18: padded staging block), even shards (the collective writes straight into the output's slices),
-    and a single rank (the collective still runs: what the one-GPU rehearsal of bench.py executes)"""
+    a single rank (the collective still runs: what the one-GPU rehearsal of bench.py executes), and WORLD SIZE 8 -- the size of
+    the first 8-GPU run -- with uneven (5 x 8 + 3 x 7) and even shards"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    g_obs, g_done = q.get(timeout=120)
+    g_obs, g_done = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     from helpers import make_config
     from gym_os2r_amd import abi

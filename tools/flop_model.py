@@ -26,8 +26,17 @@ a row with nz non-zeros is nz FMA for the residual, one FMA for the impulse, one
 a joint row starts its residual with a MUL), times 64 lanes:
       k_sweep      = 64 * sum over the joints j of (4 (j + 1) + 2)               (the joint-friction rows of one sweep)
       k_body_sweep = 64 * mean over the bodies that can touch of 3 (4 (b + 1) + 3)   (the three rows of one contact)
-and only launch_wave, scanned_body, row_body and exact_solve are fitted (non-negative least squares on what the fixed
-units leave).  `fit` refuses a result that prices a solver unit at zero while its counter is not, and reports the residual.
+Round 5: `scanned_body` and `row_body` are collinear in the steady state (both 3.0 per wave-iteration) and the
+fit priced the same code on the same robot 4.6 k / 24.0 k lane-flops in C4 against 11.9 k / 11.2 k in C3.  They are now priced
+from the source's operation count as well (FMA = 2, MUL = ADD = 1; min / max, compares, selects and the reciprocal estimate are not
+in the PMC counters; a Newton reciprocal `rcp_t` is 4 FMA):
+      k_scanned_body(b) = 64 * (9 * candidates_b + 5 * runs_b + 4)     (scan of the compiled-in models: per candidate two FMA for the
+                          height, an ADD for the run's weight, two FMA for the moments; per run of equal coordinates an ADD and two FMA)
+      k_row_body(b)     = 64 * (59 + 15 (b + 1) + 3 b (b + 1) + 6 b)   (contact point, Jacobian rows of b + 1 joints, G = J Lc, three
+                          squared norms and their reciprocals)
+each the mean over the bodies that lie on the ground in the steady state, and only `launch_wave` and `exact_solve` are fitted
+(non-negative least squares on what the fixed units leave).  Workloads that share a robot share these four prices by construction
+(asserted).  `fit` refuses a result that prices the solver unit at zero while its counter is not, and reports the residual.
 """
 import argparse
 import csv
@@ -95,6 +104,28 @@ def sweep_prices(workload, nbodies=None):
     return 64.0 * joint, 64.0 * contact
 
 
+def geometry_prices(workload, nbodies=None):
+    """(lane-flops of one body's candidate scan, of one body's contact-row set-up) x 64 lanes from the operation count of
+    os2r_device.hpp (step 5 of substep), means over the `nbodies` most distal bodies that can touch"""
+    import bench
+    import numpy as np
+    import gym_os2r_amd as g
+    mode = bench.WORKLOADS[workload][0]
+    model = g.get_model(g.config.SettingsConfig().get_config(f"task_modes/{mode}/model"))
+    cb = np.array([int(b) for b in model["cand_body"]])
+    cp = np.array(model["cand_p"], dtype=float)
+    bodies = sorted(set(cb.tolist()))
+    if nbodies:
+        bodies = bodies[-int(nbodies):]
+    scan, rows = [], []
+    for b in bodies:
+        p = cp[cb == b]
+        runs = min(1 + int((p[1:, a] != p[:-1, a]).sum()) for a in range(3))   # CandMeta: the coordinate with the fewest runs
+        scan.append(9 * len(p) + 5 * runs + 4)
+        rows.append(59 + 15 * (b + 1) + 3 * b * (b + 1) + 6 * b)
+    return 64.0 * sum(scan) / len(scan), 64.0 * sum(rows) / len(rows)
+
+
 def pmc_per_launch(d):
     """{counter: [value per step-kernel dispatch, in dispatch order]} from a rocprofv3 --pmc output directory"""
     acc = {}
@@ -124,13 +155,14 @@ def fit(src, dst):
         # the sweep units from the source's operation count (see the header); the model of the workload gives the bodies
         in_form = int(round(float(np.median(X[-200:, 2])) / (waves * 10.0)))     # bodies with rows per wave and iteration, steady state
         k_sweep, k_body = sweep_prices(wl, max(in_form, 1))
-        fixed = k_body * X[:, 3] + k_sweep * X[:, 4]
-        free = [0, 1, 2, 5]
+        k_scan, k_rows = geometry_prices(wl, max(in_form, 1))
+        fixed = k_body * X[:, 3] + k_sweep * X[:, 4] + k_scan * X[:, 1] + k_rows * X[:, 2]
+        free = [0, 5]
         Xf = X[:, free]
         scale = np.maximum(Xf.max(axis=0), 1.0)
         kf, _ = nnls(Xf / scale, np.maximum(y - fixed, 0.0))          # prices cannot be negative (the regressors are correlated in time)
         kf = kf / scale
-        k = np.array([kf[0], kf[1], kf[2], k_body, k_sweep, kf[3]])
+        k = np.array([kf[0], k_scan, k_rows, k_body, k_sweep, kf[1]])
         res = (X @ k - y) / y
         names = ["launch_wave", "scanned_body", "row_body", "body_sweep", "sweep", "exact_solve"]
         for j, nm in enumerate(names):
@@ -140,12 +172,17 @@ def fit(src, dst):
                                     "rel_residual_max": float(np.abs(res).max()),
                                     "flops_per_env_step_first_20": float(y[:20].mean() / counts["envs"]),
                                     "flops_per_env_step_last_200": float(y[-200:].mean() / counts["envs"])},
-                            "source": f"profiles/flop_model.json[{wl}_f64]: sweep units from the source's operation count, the others by least squares of 64*(2*FMA+MUL+ADD) "
+                            "source": f"profiles/flop_model.json[{wl}_f64]: sweep, scan and row units from the source's operation count, launch_wave and exact_solve by least squares of 64*(2*FMA+MUL+ADD) "
                                       f"(rocprofv3 --pmc, per launch) on the work counters of the same {n} launches from the reset"}
         md.append(f"## {wl} (f64, {counts['envs']} envs, {n} launches from the reset)\n")
         md.append("| unit | lane-flops per unit |\n|---|---|\n" + "".join(f"| {a} | {b:.1f} |\n" for a, b in zip(names, k)))
         md.append(f"\nrelative residual per launch: rms {np.sqrt((res ** 2).mean()):.2e}, max {np.abs(res).max():.2e}; PMC flops per env-step: "
                   f"{y[:20].mean() / counts['envs']:.0f} (first 20 launches after the reset), {y[-200:].mean() / counts['envs']:.0f} (last 200)\n")
+    # workloads on the same robot price the units that are counted from the source alike
+    if "C3_f64" in out and "C4_f64" in out:
+        for nm in ("scanned_body", "row_body", "body_sweep", "sweep"):
+            a_, b_ = out["C3_f64"]["flops_per_unit"][nm], out["C4_f64"]["flops_per_unit"][nm]
+            assert abs(a_ - b_) <= 0.1 * max(a_, b_), (nm, a_, b_)
     # bench.py reads the entry of its workload; keep one flat default for C4
     with open(dst + ".json", "w") as f:
         json.dump(out, f, indent=1)

@@ -12,7 +12,7 @@ for r in 1 2 3; do
   for w in "$@"; do
     for lv in $LIBS; do
       label=${lv%%=*}; lib=${lv#*=}
-      OS2R_LIBRARY=$ROOT/$lib timeout -k 10 300 python bench.py --no-cpu-baseline --no-count $w > "$OUT/bench_$label.json" 2>"$OUT/err_$label.log" || { echo "FAILED $label [$w]"; tail -3 "$OUT/err_$label.log"; exit 1; }
+      OS2R_LIBRARY=$ROOT/$lib timeout -k 10 300 python bench.py --no-cpu-baseline --no-count --no-gym-level $w > "$OUT/bench_$label.json" 2>"$OUT/err_$label.log" || { echo "FAILED $label [$w]"; tail -3 "$OUT/err_$label.log"; exit 1; }
       python -c "import json;d=json.load(open('$OUT/bench_$label.json'));print('$label [$w]', round(d['value']/1e6,1), 'M/s', round(d['ms_per_step']*1e3,2), 'us/step', 'kernel', round(d['roofline']['kernel_ms_per_launch']*1e3,2), 'us')" | tee -a "$OUT/table.txt"
     done
   done

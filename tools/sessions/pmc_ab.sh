@@ -16,7 +16,7 @@ for lv in $LIBS; do
              "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_WAVES" \
              "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES"; do
     rm -rf "$OUT/pmc_tmp"
-    timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_tmp" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-count --steps 200 --warmup 20 "$@" > "$OUT/$label.log" 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_tmp" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-count --no-gym-level --steps 200 --warmup 20 "$@" > "$OUT/$label.log" 2>&1
     python3 - "$OUT/pmc_tmp" "$label" <<'PY' | tee -a "$OUT/pmc_table.txt"
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
