@@ -687,7 +687,13 @@ int os2r_bench_steps(Os2rSim* sim, int nsteps, void* stream, float* elapsed_ms) 
   }
   if (!elapsed_ms) return OS2R_OK;   // enqueue only: several handles on several streams are timed by their caller
   HIP_TRY(sim, hipEventRecord(sim->ev1, st));
-  HIP_TRY(sim, hipEventSynchronize(sim->ev1));
+  // the caller's clock runs until this returns: poll the event instead of sleeping on it (a blocked host thread is woken tens of
+  // microseconds after the last launch has finished -- 1-2 % of a 20-step window)
+  for (;;) {
+    const hipError_t q = hipEventQuery(sim->ev1);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) { sim->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return OS2R_ERR_HIP; }
+  }
   HIP_TRY(sim, hipEventElapsedTime(elapsed_ms, sim->ev0, sim->ev1));
   return OS2R_OK;
 }

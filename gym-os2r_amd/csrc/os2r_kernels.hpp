@@ -541,6 +541,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     const OS2R_CONST StepArgs<T>* args_e = (const OS2R_CONST StepArgs<T>*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(args_e));
     const StepArgs<T>& Ae = *(const StepArgs<T>*)args_e;
+    // (This reads the argument segment at offset 0: every kernel that inlines step_body -- step_kernel below, the run-time
+    // code objects of os2r_jit_unit.hip -- takes ONE argument, the StepArgs by value.  A wrapper with another leading argument
+    // would read garbage here; the counting variants, which the tests and bench.py's replay run, check it and trap.)
+    if constexpr (COUNT) {
+      if (Ae.N != A.N || Ae.q != A.q || Ae.solver_l != A.solver_l) __builtin_trap();
+    }
     // The contact solver's state goes back to HBM here, straight after the last physics iteration: held until the end of
     // the env-step it would be live across the whole epilogue -- forty registers more at the kernel's widest point.
     if constexpr (kCarry) {

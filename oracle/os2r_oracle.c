@@ -573,6 +573,8 @@ static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_s
 static double g_incons = 1e-4, g_stall = 0.0;
 static int g_pivot = 0;                  /* 1: an inconsistent-set step that would pin a row it has pinned before in this iteration ends phase 2 instead (round 5) */
 void orc_set_experimental_pivot(int on) { g_pivot = on; }
+static int g_repin = 0;                  /* 1: a cut step puts every row back that the last sweep released from a bound and that violates the same bound again, at once (round 5) */
+void orc_set_experimental_repin(int on) { g_repin = on; }
 static int g_equil = 1;                  /* the regularised solve takes every free row with the weight 1 / |g_r|^2 (the specification since round 5; 0: round 4) */
 void orc_set_experimental_equil(int on) { g_equil = on; }
 static int g_prox_later = 0;             /* proximal iterations of an environment's second and later solves of an iteration (0: g_prox) */
@@ -600,7 +602,7 @@ long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = 
 #else
 enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
-       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1 };
+       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0 };
 static const double g_incons = 1e-4, g_stall = 0.0;
 #endif
 
@@ -865,6 +867,7 @@ static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu
 
 static _Thread_local int tl_incons_steps = 0;   /* steps to the first bound of an inconsistent free set taken so far in this iteration */
 static int warm_slot(const Row* rows, int r);
+static _Thread_local unsigned tl_was_lo = 0u, tl_was_hi = 0u;   /* rows (by index) that sat on their lower / upper bound before the last sweep */
 static _Thread_local unsigned tl_incons_pinned = 0u;   /* rows (by warm slot) that such steps have set on a bound in this iteration */
 #ifdef ORC_EXPERIMENTS
 /* laboratory diagnostics (orc_debug_free_set_hist): the shape of the free set of every exact solve, by the solve's index within its
@@ -1045,6 +1048,24 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     for (int r = 0; r < nr; ++r) if (fr[r]) { double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi); const double full = rows[r].lambda + mu[r]; nviol += full < lo || full > hi; }
     trace_solve(rows, nr, fr, mu, alpha, cut, on, nviol, found, left);
   }
+  if (g_repin && cut && !on) {
+    /* EXPERIMENT (round 5): the re-test sweep released rows from their bounds that the very next full step sends back beyond the
+     * same bound: instead of cutting the step at the first of them (a solve per row, at step lengths of 1e-5 .. 1e-2), all of them
+     * are put back on their bounds at once -- the velocity following row by row, no step taken -- and the solve repeats */
+    int n_back = 0;
+    for (int r = 0; r < nr; ++r) {
+      if (!fr[r]) continue;
+      double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+      const double full = rows[r].lambda + mu[r];
+      const int back_lo = full < lo && ((tl_was_lo >> r) & 1u), back_hi = full > hi && ((tl_was_hi >> r) & 1u);
+      if (!back_lo && !back_hi) continue;
+      const double nl = back_lo ? lo : hi, dl = nl - rows[r].lambda;
+      rows[r].lambda = nl;
+      for (int j = 0; j < n; ++j) v[j] += rows[r].T[j] * dl;
+      ++n_back;
+    }
+    if (n_back > 0) return 1;
+  }
   if (g_clamp_all && cut && !on) {
     /* EXPERIMENT: a step that a bound cuts short is taken in full, every row clamped into its own box (all violators are
      * set on their bounds at once, a primal-dual active-set step), the velocity following row by row */
@@ -1196,6 +1217,14 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         ++rounds;
       }
       if (phase == 1) tl_last_sweeps = it + 1;
+      if (phase == 1 && g_repin) {
+        tl_was_lo = tl_was_hi = 0u;
+        for (int r = 0; r < nr && r < 32; ++r) {
+          double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+          if (rows[r].d > 0.0 && rows[r].lambda <= lo) tl_was_lo |= 1u << r;
+          if (rows[r].d > 0.0 && rows[r].lambda >= hi) tl_was_hi |= 1u << r;
+        }
+      }
       double moved = 0.0;
       for (int ri = 0; ri < nr; ++ri) {
         const int r = (phase == 1 && !g_block_solve) ? order[ri] : ri;

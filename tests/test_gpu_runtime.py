@@ -251,6 +251,15 @@ def test_bench_prints_the_contract_line():
     assert abs(d["value"] - 65536 * 30 / (d["ms_per_step"] * 30 * 1e-3)) / d["value"] < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # round 5: the surface users call and the open-loop rollout line in the same record, both byte counts
+    gl, ro = d["gym_level"], d["rollout"]
+    for k in ("value", "unit", "frac_of_value", "us_per_step", "steps", "host_us_per_call", "surface"):
+        assert k in gl, k
+    assert gl["unit"] == "env-steps/s" and gl["steps"] == 300 and 0.5 < gl["frac_of_value"] < 1.2 and 0 < gl["host_us_per_call"] < 150
+    assert abs(gl["value"] - 65536 * gl["steps"] / (gl["us_per_step"] * 1e-6 * gl["steps"])) / gl["value"] < 1e-6
+    assert ro["K"] == 10 and ro["value"] > 0 and ro["unit"] == "env-steps/s"
+    assert r["algorithmic_bytes_survey"] == 465 and r["algorithmic_bytes_per_env_step"] == 862    # 233 B in fp32 for C4; in fp64 everything doubles but the flag byte
+    assert abs(r["frac_survey"] - r["achieved_survey"] / r["peak"]) < 1e-12 and r["frac_survey"] < r["frac"]
 
 
 def test_plain_cpp_program_drives_the_c_abi(torch_mod, tmp_path):

@@ -21,7 +21,17 @@ from gym_os2r_amd.randomizers.monopod import MonopodEnvRandomizer
 ENV_ID = "Monopod-hop-v1"   # free_hip model; with the randomizer wrapper this is the C4 physics (contact + DR + random resets)
 
 
+ACTS = {}
+
+
 def timed(fn, steps, warm=30):
+    # a fresh U(-1, 1) action tensor for EVERY step, as a policy would hand over, generated before the clock starts (views of one
+    # block: no policy kernels in the way).  Holding one action for hundreds of steps is another workload (513 us per step at
+    # 65 536 environments against 147: the robots are driven into the ground), and so is cycling through a few dozen tensors
+    # (the regime drifts by +-5 %: the first version of this table compared surfaces across that drift)
+    a = ACTS["make"](steps + warm)
+    it = iter(a)
+    ACTS["next"] = lambda: next(it)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -43,14 +53,10 @@ def surfaces(n, steps, preroll):
     rt = env.unwrapped
     sim = rt.sim
     sim.bench_steps(preroll)                   # the stationary regime (every robot on the ground), as bench.py
-    # fresh actions every step, as a policy would give them, but without a policy's kernels in the way: views of one tensor
-    # (holding ONE action for hundreds of steps is another workload: 513 us per step at 65 536 envs against 147)
-    acts = torch.rand(64, n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1
-    k = [0]
+    ACTS["make"] = lambda m: torch.rand(m, n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1
 
     def act():
-        k[0] += 1
-        return acts[k[0] & 63]
+        return ACTS["next"]()
 
     ms = sim.bench_steps(steps)
     out.append(("bare C-ABI loop, os2r_bench_steps (device RNG actions)", n * steps / (ms * 1e-3), ms / steps * 1e3, 0.0))
@@ -67,7 +73,7 @@ def surfaces(n, steps, preroll):
     out.append(("randomizer wrapper .step", n * steps / w, w / steps * 1e6, h / steps * 1e6))
 
     def with_policy():
-        a = torch.rand(n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1     # a 'policy' on the device
+        a = torch.rand(n, 2, dtype=obs.dtype, device=obs.device) * 2 - 1     # a 'policy' on the device: three small kernels per step
         _, _, _, info = env.step(a)
         _ = info["terminal_observation"]
     w, h = timed(with_policy, steps)

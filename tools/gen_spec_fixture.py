@@ -42,10 +42,22 @@ def run(case):
             f"{name}/reward_sum": np.sum(rews, axis=0), f"{name}/done_count": np.sum(np.array(dones) != 0, axis=0)}
 
 
+def toolchain():
+    """What built and runs the oracle here: compiler and C library (the fixture records it; on another toolchain 1-ulp differences
+    of libm's sin / cos can flip a done flag of a flailing robot, and the drift test allows for that)."""
+    import platform
+    import subprocess
+    try:
+        cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        cc = "gcc ?"
+    return f"{cc}; libc {'-'.join(platform.libc_ver())}; {platform.machine()}"
+
+
 def main():
     from oracle import oracle_py
     oracle_py.build()
-    out = {}
+    out = {"toolchain": np.array(toolchain())}
     for c in CASES:
         out.update(run(c))
     path = os.path.join(ROOT, "tests", "golden", "spec_trajectories.npz")
