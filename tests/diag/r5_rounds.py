@@ -42,6 +42,8 @@ def rounds(L, a, settings):
         workload = a.workload; envs_per_gpu = a.envs; dtype = "f64"; seed = 42
         pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
+    if "tol" in settings:               # (a configuration value, not a switch: `tol=1e-20`)
+        cfg.pgs_tol = float(settings["tol"])
     apply(L, {})                       # the preroll is the specification's for every variant: the same states
     o = O.OracleSim(cfg, threads=os.cpu_count() or 1)
     for _ in range(a.preroll):
@@ -94,7 +96,8 @@ def closed_loop(L, settings):
     global _REF
     if "_REF" not in globals():
         _REF = run({}, pgs_iters=300, pgs_exact=100, pgs_tol=0.0)
-    e = np.max(np.abs(run(settings) - _REF) / np.maximum(np.abs(_REF), 1.0), axis=0)
+    kw = {"pgs_tol": float(settings["tol"])} if "tol" in settings else {}
+    e = np.max(np.abs(run(settings, **kw) - _REF) / np.maximum(np.abs(_REF), 1.0), axis=0)
     print(f"  closed loop, 1000 balancing env-steps vs the converged solve: median {np.median(e):.1e}  p90 {np.percentile(e, 90):.1e}  p99 {np.percentile(e, 99):.1e}  max {e.max():.1e}")
 
 
@@ -113,7 +116,7 @@ def main():
         settings = {}
         for kv in filter(None, rest.split(",")):
             k, _, val = kv.partition("=")
-            settings[k] = SWITCHES[k][1](val)
+            settings[k] = float(val) if k == "tol" else SWITCHES[k][1](val)
         print(f"{name}  {settings}  [{a.workload}, {a.envs} envs, {a.steps} env-steps after {a.preroll}]")
         rounds(L, a, settings)
         if a.closed_loop:
