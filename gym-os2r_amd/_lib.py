@@ -36,6 +36,10 @@ def load():
         raise Os2rLibraryMissing(
             f"{LIB_PATH} not found: build the HIP extension first (make -C gym-os2r_amd/csrc). "
             "The stepper has no CPU fallback.")
+    # torch first: the library needs libamdhip64, and the process must hold ONE HIP runtime -- the one torch brings.  Loaded before
+    # torch (e.g. build() and smoke() of __graft_entry__ in one process) the library pulls in the system's runtime, torch then
+    # its own, and os2r_create sees no device through the first ("no HIP device visible").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, u8p = C.c_void_p, C.c_void_p
     lib.os2r_abi_version.restype = C.c_int

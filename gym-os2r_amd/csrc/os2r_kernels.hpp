@@ -501,7 +501,8 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& A) {
     if (A.actions) {
       ax = A.actions[2 * (ko + e)];
       ay = A.actions[2 * (ko + e) + 1];
-      const bool outside = ax < T(-1) || ax > T(1) || ay < T(-1) || ay > T(1);
+      // (the lanes behind the last environment of a tail wave shadow it and must not count its action again)
+      const bool outside = (ax < T(-1) || ax > T(1) || ay < T(-1) || ay > T(1)) && e0 + lane < A.N;
       if (__ballot(outside) != 0ull && outside && A.violations) atomicAdd(A.violations, 1u);
     } else {
       double u0, u1;

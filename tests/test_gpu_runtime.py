@@ -227,6 +227,47 @@ def test_device_actions_are_validated_without_stalling(torch_mod):
 
 
 @pytest.mark.gpu
+def test_done_mask_and_violation_mirror_come_out_of_the_step_launch(torch_mod):
+    """ABI 5 (include/os2r.h): os2r_set_done_mask -- the launch writes the boolean `done` next to the flag bits, through both
+    bindings --; os2r_get_violation_mirror -- the first wave of a launch stores, in pinned host memory, the count of clamped caller
+    actions as EARLIER launches left it and the launch's own step counter: after launch k + 1 has started the verdict on step k is a
+    host load away.  And the mask is not written by os2r_rollout, nor left registered behind a step."""
+    n = 1000                                           # a tail wave: 1000 = 15 x 64 + 40
+    for binding in ("ctypes", "pybind11"):
+        rt = g.make("Monopod-balance-v1", num_envs=n, seed=3, max_episode_steps=7)
+        rt.reset()
+        sim = rt.sim if binding == "ctypes" else None
+        if binding == "pybind11":
+            from gym_os2r_amd.sim import HipSim
+            sim = HipSim(rt.sim.cfg, binding="pybind11")
+        gen = torch_mod.Generator(device="cuda").manual_seed(5)
+        m = sim.violation_mirror()
+        assert m.shape == (2,) and int(m[0]) == 0
+        k0 = sim.step_count
+        seen_done = False
+        for t in range(12):
+            a = torch_mod.rand(n, 2, generator=gen, device="cuda", dtype=torch_mod.float64) * 2 - 1
+            if t == 4:
+                a[3, 0] = 1.5; a[999, 1] = -2.0       # two environments out of range: clamped and counted by launch k0 + 4
+            obs, rew, flags, term, mask = sim.step(a, want_mask=True)
+            torch_mod.cuda.synchronize()
+            assert mask.dtype == torch_mod.bool and torch_mod.equal(mask, flags != 0)
+            seen_done |= bool(mask.any())
+            # launch k0 + t has started (it has finished): the mirror holds ITS step counter and what the launches before it left
+            assert int(m[1]) == (k0 + t) & 0xFFFFFFFF
+            assert int(m[0]) == (2 if t >= 5 else 0)
+        assert seen_done                               # the TimeLimit of 7 steps fired: the mask is not all zeros
+        # a plain step afterwards must not write a mask anywhere (the handle keeps no pointer), and a rollout never does
+        obs, rew, flags, term = sim.step(None)
+        o2 = sim.rollout(3)
+        torch_mod.cuda.synchronize()
+        assert int(m[1]) in (k0 + 13, k0 + 15)         # the fused rollout's one launch carries the counter of its first step (three launches: of its last)
+        rt.close()
+        if binding == "pybind11":
+            sim.close()
+
+
+@pytest.mark.gpu
 def test_bench_prints_the_contract_line():
     """bench.py: one JSON line with the contract keys, the roofline objects and the CPU baseline (short run)."""
     import json

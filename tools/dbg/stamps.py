@@ -20,8 +20,8 @@ PHASES = ["sincos", "ABA passes", "inverse mass matrix", "whitening (Cholesky, y
           "contact: candidate scan", "contact: row setup (+ FK of next body)", "PGS phase 1", "PGS phase 2", "map back + integrate", "prologue (once per env-step)", "epilogue: state stores (once per env-step)",
           "  dyn: body velocities", "  dyn: inward body 4", "  dyn: inward body 3", "  dyn: inward body 2", "  dyn: inward body 1",
           "  dyn: inward body 0", "PGS phase 2: exact solves", "  Minv: inward", "epilogue: guard + history loads (once)", "epilogue: observation (once)", "epilogue: reward (once)", "epilogue: done, reset, obs store (once)",
-          "  exact solve: pass 1 (S, h)", "  exact solve: factorisation + proximal solves", "  exact solve: pass 2 (impulses, cut test)", "  exact solve: step length", "  exact solve: apply", "  exact solve: free-row mask + dual solve of small sets"]
-COLS = list(range(24)) + list(range(26, 32))   # the columns that are phases (24 / 25: the wave's life on the two clocks)
+          "  exact solve: pass 1 (S, h)", "  exact solve: factorisation + proximal solves", "  exact solve: pass 2 (impulses, cut test)", "  exact solve: step length", "  exact solve: apply"]
+COLS = list(range(24)) + list(range(26, 31))   # the columns that are phases (24 / 25: the wave's life on the two clocks)
 NS = 32   # kStamps in os2r_device.hpp
 
 
