@@ -37,6 +37,14 @@ __global__ __launch_bounds__(64) void k(const double* __restrict__ in, double* _
   unsigned long long t_serial = 0, t_coop = 0;
   double sink = 0.0;
   for (int rep = 0; rep < reps; ++rep) {
+    // (the rows are opaque to the optimiser in every repetition: otherwise the products that do not depend on y are hoisted out of
+    // the loop and the serial form is timed at a third of its instructions)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) asm volatile("" : "+v"(g[r][i]));
+      asm volatile("" : "+v"(c[r]), "+v"(t[r]));
+    }
     // ---- serial: the live lane alone ----
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long a0 = __builtin_amdgcn_s_memtime();
