@@ -593,9 +593,16 @@ def main():
             out["roofline_valu"]["specification_flops_per_env_step"] = spec["flops_per_env_step"]
         if world == 1 and S == 1 and args.rollout == 0 and not args.gather_obs and not args.no_gym_level and not getattr(args, "runtime_model", False):
             # computed after the timed region, like cpu_baseline: the surface users call, and the open-loop rollout line
-            ck_g = cks[0] if cks else sim.checkpoint()
-            out["rollout"] = rollout_line(args, sim)
-            out["gym_level"] = gym_level(args, cfg, ck_g, value)
+            # (add-on measurements: a failure here is recorded, it does not take the headline with it)
+            try:
+                ck_g = cks[0] if cks else sim.checkpoint()
+                out["rollout"] = rollout_line(args, sim)
+            except Exception as e:                    # noqa: BLE001
+                out["rollout"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                out["gym_level"] = gym_level(args, cfg, ck_g, value)
+            except Exception as e:                    # noqa: BLE001
+                out["gym_level"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(out), flush=True)
