@@ -573,6 +573,8 @@ static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_s
 static double g_incons = 1e-4, g_stall = 0.0;
 static int g_pivot = 0;                  /* 1: an inconsistent-set step that would pin a row it has pinned before in this iteration ends phase 2 instead (round 5) */
 void orc_set_experimental_pivot(int on) { g_pivot = on; }
+static int g_multicut = 0;               /* k > 0: a step that is cut below 1e-k of its length pins every row that would reach its bound within 10 x that fraction, no step taken (round 5) */
+void orc_set_experimental_multicut(int k) { g_multicut = k; }
 static int g_repin = 0;                  /* 1: a cut step puts every row back that the last sweep released from a bound and that violates the same bound again, at once (round 5) */
 void orc_set_experimental_repin(int on) { g_repin = on; }
 static int g_equil = 1;                  /* the regularised solve takes every free row with the weight 1 / |g_r|^2 (the specification since round 5; 0: round 4) */
@@ -602,7 +604,7 @@ long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = 
 #else
 enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
-       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0 };
+       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0 };
 static const double g_incons = 1e-4, g_stall = 0.0;
 #endif
 
@@ -862,6 +864,16 @@ static void trace_solve(const Row* rows, int nr, const int* fr, const double* mu
     *b++ = c;
   }
   b += snprintf(b, (size_t)(e - b), "] a=%.3g%s%s v%d f=%.1e l=%.1e", alpha, cut ? " cut" : "", incons ? " incons" : "", nviol, found, left);
+  if (getenv("ORC_TRACE_ROOM")) {   /* how far inside its box every free boxed row sits, as a fraction of the box's width */
+    b += snprintf(b, (size_t)(e - b), " room{");
+    for (int r = 0; r < nr && b < e; ++r) {
+      if (!fr[r] || rows[r].kind == 0) continue;
+      double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+      const double room = fmin(rows[r].lambda - lo, hi - rows[r].lambda) / (hi - lo);
+      b += snprintf(b, (size_t)(e - b), "%d:%.1e ", r, room);
+    }
+    b += snprintf(b, (size_t)(e - b), "}");
+  }
   tl_trace_len = (int)(b - tl_trace);
 }
 
@@ -1047,6 +1059,23 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     int nviol = 0;
     for (int r = 0; r < nr; ++r) if (fr[r]) { double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi); const double full = rows[r].lambda + mu[r]; nviol += full < lo || full > hi; }
     trace_solve(rows, nr, fr, mu, alpha, cut, on, nviol, found, left);
+  }
+  if (g_multicut > 0 && cut && !on && alpha < pow(10.0, -g_multicut)) {
+    /* EXPERIMENT (round 5): a step that a bound cuts at a ten-thousandth of its length moves nothing; the rows that cut it sit a hair
+     * inside boxes that the full step would leave by hundreds of their widths (a robot at rest: sliding contacts whose friction box
+     * moved by a hair, joints on the edge of sticking).  All of them -- every free row whose own bound is reached within 10 x the
+     * cut fraction -- are set on their bounds at once, the velocity following row by row, and the solve repeats */
+    for (int r = 0; r < nr; ++r) {
+      if (!fr[r] || mu[r] == 0.0) continue;
+      double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+      if (mu[r] > 0.0 && !isfinite(hi)) continue;
+      const double lim = ((mu[r] > 0.0 ? hi : lo) - rows[r].lambda) / mu[r];
+      if (lim > 10.0 * alpha) continue;
+      const double nl = mu[r] > 0.0 ? hi : lo, dl = nl - rows[r].lambda;
+      rows[r].lambda = nl;
+      for (int j = 0; j < n; ++j) v[j] += rows[r].T[j] * dl;
+    }
+    return 1;
   }
   if (g_repin && cut && !on) {
     /* EXPERIMENT (round 5): the re-test sweep released rows from their bounds that the very next full step sends back beyond the
