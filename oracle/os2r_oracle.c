@@ -573,6 +573,10 @@ static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_s
 static double g_incons = 1e-4, g_stall = 0.0;
 static int g_pivot = 0;                  /* 1: an inconsistent-set step that would pin a row it has pinned before in this iteration ends phase 2 instead (round 5) */
 void orc_set_experimental_pivot(int on) { g_pivot = on; }
+static int g_snap = 0;                   /* 1: the warm start puts a tangential row that ended the last iteration ON a bound on the same bound of this iteration's box (round 5; within an env-step only) */
+void orc_set_experimental_snap(int on) { g_snap = on; }
+static int g_solve_first = 0;            /* k > 0: a physics iteration whose predecessor IN THE SAME env-step took >= k exact solves skips the first sweeps and opens with a solve (round 5) */
+void orc_set_experimental_solve_first(int k) { g_solve_first = k; }
 static int g_multicut = 0;               /* k > 0: a step that is cut below 1e-k of its length pins every row that would reach its bound within 10 x that fraction, no step taken (round 5) */
 void orc_set_experimental_multicut(int k) { g_multicut = k; }
 static int g_repin = 0;                  /* 1: a cut step puts every row back that the last sweep released from a bound and that violates the same bound again, at once (round 5) */
@@ -604,7 +608,7 @@ long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = 
 #else
 enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
-       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0 };
+       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0, g_snap = 0, g_solve_first = 0 };
 static const double g_incons = 1e-4, g_stall = 0.0;
 #endif
 
@@ -1148,6 +1152,9 @@ static _Thread_local int tl_last_sweeps = 0, tl_last_solves = 0;
 #define ORC_WARM_SLOTS (ORC_WARM_ROWS + 1)   /* the last slot: 1.0 once an iteration has left its impulses (the joint rows are remembered) */
 /* first > 0: that many sweeps before the first check; first = -k: k - 1 sweeps, then EVERY environment solves once before its first check */
 static _Thread_local double tl_warm[ORC_WARM_SLOTS];
+static _Thread_local int tl_prev_opened = 0;
+static _Thread_local int tl_prev_solves = 0;   /* (g_solve_first) exact solves of the previous physics iteration of this env-step */
+static _Thread_local signed char tl_warm_side[ORC_WARM_SLOTS];   /* (g_snap) -1 / +1: the row ended the last iteration on its lower / upper bound */
 static _Thread_local int tl_cold = 0;   /* modes 0 and 2 only */
 static void warm_forget(double* w) { for (int k = 0; k < ORC_WARM_SLOTS; ++k) w[k] = NAN; }
 static int warm_slot(const Row* rows, int r) {
@@ -1217,6 +1224,7 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
         if (!(R->d > 0.0) || isnan(w0)) continue;
         double lo, hi; row_box(rows, R, 1, &lo, &hi);
         double nl = w0 < lo ? lo : (w0 > hi ? hi : w0);
+        if (g_snap && R->kind == 1 && tl_warm_side[warm_slot(rows, r)] != 0) nl = tl_warm_side[warm_slot(rows, r)] > 0 ? hi : lo;
         const double dl = nl - R->lambda;
         R->lambda = nl;
         for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
@@ -1229,10 +1237,13 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
 #ifdef ORC_EXPERIMENTS
     if (g_trace < 0) { const char* t = getenv("ORC_TRACE_SOLVES"); g_trace = t ? atoi(t) : 0; }
 #endif
+    /* (laboratory) an iteration opens with a solve when its predecessor took >= g_solve_first solves, and goes on doing so while that takes exactly one */
+    const int first_now = (g_solve_first && phase == 1 && exact > 0 && (tl_prev_solves >= g_solve_first || (tl_prev_opened && tl_prev_solves == 1))) ? 0 : ORC_EXACT_FIRST(n);
+    if (phase == 1) tl_prev_opened = first_now == 0 && g_solve_first;
     for (int it = 0; it < sweeps; ++it) {
       /* exact finish: from the check after the first ORC_EXACT_FIRST sweeps on, solves (repeated while a bound cuts
        * the step short) precede every sweep until the budget `exact` is spent */
-      if (phase == 1 && exact > 0 && it >= ORC_EXACT_FIRST(n) && solves < exact) {
+      if (phase == 1 && exact > 0 && it >= first_now && solves < exact) {
         int blocked = 1;
         while (blocked && solves < exact) {
 #ifdef ORC_EXPERIMENTS
@@ -1274,13 +1285,13 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       }
       if (phase == 1) trace_sweep(moved);
       /* EXPERIMENT: a round (solves + re-test sweep) that does not bring the measure below g_stall of the last one ends phase 2 */
-      if (phase == 1 && exact > 0 && g_stall > 0.0 && solves > 0 && it + 1 > ORC_EXACT_FIRST(n)) {
+      if (phase == 1 && exact > 0 && g_stall > 0.0 && solves > 0 && it + 1 > first_now) {
         if (solves > solves_at_measure && e_prev >= 0.0 && moved > g_stall * e_prev && (!g_stall_incons_only || tl_incons_steps > incons_at_measure)) { break; }
       }
       if (phase == 1) { e_prev = moved; solves_at_measure = solves; incons_at_measure = tl_incons_steps; }
       if (phase == 1 && exact > 0 && g_max_rounds > 0 && (rounds >= g_max_rounds || (g_stop_at_cap && solves >= exact))) break;   /* experiment: bounded rounds */
       if (phase == 1 && it + 1 < sweeps && moved <= tol) {
-        if (exact > 0 ? it + 1 >= ORC_EXACT_FIRST(n) && !(g_solve_always && solves == 0) : (it + 1) % ORC_PGS_GROUP == 0) break;
+        if (exact > 0 ? it + 1 >= first_now && !(g_solve_always && solves == 0) : (it + 1) % ORC_PGS_GROUP == 0) break;
       }
     }
     if (phase == 1 && g_trace > 0 && solves >= g_trace) { tl_trace[tl_trace_len] = 0; fprintf(stderr, "solves %d sweeps %d:%s\n", solves, tl_last_sweeps, tl_trace); }
@@ -1303,10 +1314,16 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       if (f) { fwrite(buf, 1, (size_t)o, f); fclose(f); }
     }
 #endif
+    if (phase == 1) tl_prev_solves = solves;
     if (phase == 1 && exact > 0 && g_warm && nr <= ORC_WARM_ROWS) {
       warm_forget(tl_warm);
       for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0) tl_warm[warm_slot(rows, r)] = rows[r].lambda;
-      tl_warm[ORC_WARM_ROWS] = 1.0;
+      for (int k = 0; k < ORC_WARM_SLOTS; ++k) tl_warm_side[k] = 0;
+      if (g_snap) for (int r = 0; r < nr; ++r) if (rows[r].d > 0.0 && rows[r].kind == 1) {
+        double lo, hi; row_box(rows, &rows[r], 1, &lo, &hi);
+        tl_warm_side[warm_slot(rows, r)] = rows[r].lambda >= hi ? 1 : (rows[r].lambda <= lo ? -1 : 0);
+      }
+      tl_warm[ORC_WARM_ROWS] = (g_solve_first && tl_prev_opened && solves == 1) ? 2.0 : 1.0;   /* (2: laboratory, the solve-first mode carried to the next env-step) */
       tl_cold = 0;
     }
   }
@@ -1572,7 +1589,8 @@ int orc_step(OrcSim* s, const double* actions, double* obs, double* reward, uint
     double q[OS2R_MAX_DOF], qd[OS2R_MAX_DOF];
     EnvParams ep; load_params(s, e, &ep);
     for (int i = 0; i < n; ++i) { q[i] = s->q[i * N + e]; qd[i] = s->qd[i * N + e]; }
-    if (g_warm == 1) { memcpy(tl_warm, s->warm + (size_t)e * ORC_WARM_SLOTS, sizeof tl_warm); tl_cold = 0; }
+    tl_prev_solves = 0; tl_prev_opened = 0;
+    if (g_warm == 1) { memcpy(tl_warm, s->warm + (size_t)e * ORC_WARM_SLOTS, sizeof tl_warm); tl_cold = 0; if (g_solve_first && tl_warm[ORC_WARM_ROWS] == 2.0) { tl_prev_opened = 1; tl_prev_solves = 1; } }
     else { warm_forget(tl_warm); tl_cold = 1; }
     for (int k = 0; k < cfg->substeps; ++k) {                                                          /* gazebo_runtime.py:70-77 */
       substep_model(cfg, s->contact_model, &ep, q, qd, tau);

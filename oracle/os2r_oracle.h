@@ -62,6 +62,8 @@ void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged frictio
 void orc_set_experimental_incons(double threshold);   /* studies: the inconsistent-free-set test's threshold (1e-4) */
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
 void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (3) */
+void orc_set_experimental_solve_first(int k);   /* studies (round 5): k > 0 -- an iteration whose predecessor in the env-step took >= k solves opens with a solve instead of the first sweeps */
+void orc_set_experimental_snap(int on);   /* studies (round 5): 1 -- the warm start keeps a tangential row that ended on a bound on the same bound of the new box */
 void orc_set_experimental_multicut(int k);   /* studies (round 5): k > 0 -- a step cut below 1e-k of its length pins every row within 10 x that fraction of its bound at once */
 void orc_set_experimental_repin(int on);   /* studies (round 5): 1 -- a cut step puts back, at once, every row the last sweep released from a bound and that violates it again */
 void orc_set_experimental_equil(int on);   /* studies: 1 (the specification since round 5) -- the regularised solve weighs every free row with 1 / |g_r|^2; 0: round 4 */

@@ -25,7 +25,7 @@ from oracle import oracle_py as O     # noqa: E402
 SWITCHES = {"small": ("orc_set_experimental_small", int, 0), "prox": ("orc_set_experimental_prox", int, 3),
             "prox_later": ("orc_set_experimental_prox_later", int, 0), "incons": ("orc_set_experimental_incons", float, 1e-4),
             "stall": ("orc_set_experimental_stall", float, 0.0), "clamp_all": ("orc_set_experimental_clamp_all", int, 0),
-            "incons_once": ("orc_set_experimental_incons_once", int, 0), "pivot": ("orc_set_experimental_pivot", int, 0), "equil": ("orc_set_experimental_equil", int, 1), "repin": ("orc_set_experimental_repin", int, 0), "multicut": ("orc_set_experimental_multicut", int, 0)}
+            "incons_once": ("orc_set_experimental_incons_once", int, 0), "pivot": ("orc_set_experimental_pivot", int, 0), "equil": ("orc_set_experimental_equil", int, 1), "repin": ("orc_set_experimental_repin", int, 0), "multicut": ("orc_set_experimental_multicut", int, 0), "snap": ("orc_set_experimental_snap", int, 0), "solve_first": ("orc_set_experimental_solve_first", int, 0)}
 
 
 def apply(L, settings):
@@ -66,11 +66,13 @@ def rounds(L, a, settings):
         big = (so_ - sm_).max(axis=2)             # regularised solves of the wave's worst lane of that kind
         allr = so_.max(axis=2)
         M.append((1050.0 * sw_.max(axis=2) + 4200.0 * big + 1400.0 * np.maximum(allr - big, 0)).sum(axis=0))
+    launch_T, launch_M = np.mean([t.max() for t in T]), np.mean([m.max() for m in M])
     T, M = np.concatenate(T), np.concatenate(M)
     o.close()
     top = int(np.max(np.nonzero(hist))) if hist.any() else 0
     print(f"  (env, iteration) pairs by solves: {hist[:top + 1]}   P(>=1) {hist[1:].sum() / hist.sum():.4f}  P(>=2) {hist[2:].sum() / hist.sum():.5f}  P(>=6) {hist[6:].sum() / hist.sum():.6f}")
     print(f"  solves per wave and env-step: mean {T.mean():.2f}  p99 {np.percentile(T, 99):.0f}  max {T.max()};   modelled phase-2 ticks: mean {M.mean() / 1e3:.1f} k  p99 {np.percentile(M, 99) / 1e3:.1f} k  max {M.max() / 1e3:.1f} k")
+    print(f"  the slowest wave of a launch, mean over the launches: {launch_T:.1f} solves, {launch_M / 1e3:.1f} k modelled ticks")
 
 
 def closed_loop(L, settings):
