@@ -72,7 +72,9 @@ constexpr int kPgsGroup = 4;
 // sweeps an environment that has not converged solves its free rows exactly -- (S + eps I) d = -G_F^T w_F with
 // S = G_F^T G_F (NQ x NQ whatever the number of free rows), eps = kExactEps * trace S, kExactProx proximal iterations,
 // impulses from the residuals -- cuts the step at the first bound it meets, and re-tests every row with one measured sweep.
-constexpr int kExactProx = 3;
+// (two proximal iterations since the rows are equilibrated -- every free row at unit length, so the regularisation is 1e-6 of each
+// row's own scale: a third changes neither the solves an environment needs nor the closed loop; three up to round 5)
+constexpr int kExactProx = 2;
 constexpr double kExactEps = 1e-6, kExactSnap = 1e-12;
 // An inconsistent free set (more sticking rows than the dof they act on) leaves a residual on its rows and multipliers
 // that move by the same amount round after round: from an environment's second solve of an iteration on, a solve that
@@ -1411,7 +1413,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // per solve -- the impulses do not move before the last pass -- branch-free, kept as one scalar bit mask
     unsigned U = 0u;
     each_row(first, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
-      U |= __ballot(is_free(l, lo, hi, upper)) != 0ull ? (1u << slot) : 0u;
+      // (a ballot per comparison: the ballot of their conjunction is lowered through a 0 / 1 register and a second compare)
+      const unsigned long long fm = __builtin_amdgcn_ballot_w64(l > lo) & (upper ? __builtin_amdgcn_ballot_w64(l < hi) : ~0ull);
+      U |= fm != 0ull ? (1u << slot) : 0u;
     });
     // pass 1: S = sum over the free rows of g g^T, h = -sum g w, w = g.y - target
     // A row that is free for none of the lanes at work here -- typically two or three of the 64 -- adds exact zeros to S
@@ -1503,7 +1507,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // pass 2: impulses of the free rows from the residuals, mu = -(K w + g.ds) / eps, and whether the full step
     // would take a row out of its box
     const T ieps = -rcp_t(eps);
-    bool cut = false;
+    // (which lanes' full step leaves a box: gathered as a lane mask in scalar registers -- a bool that is or-ed across the rows'
+    // scalar branches lives in a vector register as 0 / 1, a select and an or per row)
+    unsigned long long cut_lanes = 0ull;
     // (the variant that also measures the residuals before and after the step runs when a lane of the wave asks for it)
     T found = T(0), left = T(0);
     auto pass2 = [&](auto measure_) {
@@ -1521,7 +1527,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         const T m = opaque(r * f);
         mu_put(slot, m);
         const T full = l + m;
-        cut = cut | (full < lo) | (upper ? (full > hi) : false);
+        cut_lanes |= __builtin_amdgcn_ballot_w64(full < lo) | (upper ? __builtin_amdgcn_ballot_w64(full > hi) : 0ull);
         if constexpr (decltype(measure_)::value) {
           T wl = w;
 #pragma unroll
@@ -1535,13 +1541,14 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     };
     if (__ballot(test_consistency) != 0ull) pass2(std::true_type{});
     else pass2(std::false_type{});
-    const bool incons = test_consistency & !cut & (left > T(kExactIncons) * found);
+    const unsigned long long incons_lanes = __builtin_amdgcn_ballot_w64(test_consistency) & ~cut_lanes & __builtin_amdgcn_ballot_w64(left > T(kExactIncons) * found);
+    const bool incons = __builtin_amdgcn_inverse_ballot_w64(incons_lanes);
     OS2R_ISA_MARK(12);
     OS2R_STAMP(28);   // pass 2: impulses, cut test
     // the largest feasible fraction of the step: the wave computes it when one of its lanes needs it, and only the lanes
     // whose full step leaves a box take it
     T alpha = T(1);
-    if (__ballot(cut | incons) != 0ull) {
+    if ((cut_lanes | incons_lanes) != 0ull) {
       T a = incons ? T(kExactNoBound) : T(1);
       each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
         const T m = mu_get(slot);
@@ -1551,16 +1558,17 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         const T lim = opaque(room * rcp_t(bounded ? m : T(1)));   // same sign as m, so lim >= 0
         a = (bounded & (lim < a)) ? lim : a;
       });
-      cut = cut | (incons & (a < T(kExactNoBound)));   // the long step ends on a bound: the same as a cut
-      alpha = cut ? a : T(1);
+      cut_lanes |= incons_lanes & __builtin_amdgcn_ballot_w64(a < T(kExactNoBound));   // the long step ends on a bound: the same as a cut
+      alpha = __builtin_amdgcn_inverse_ballot_w64(cut_lanes) ? a : T(1);
     }
+    const bool cut = __builtin_amdgcn_inverse_ballot_w64(cut_lanes);
     OS2R_ISA_MARK(13);
     OS2R_STAMP(29);   // step length
     // the velocity takes the last proximal iterate (exact on the free rows), the impulses their multipliers; a row
     // that the cut step has taken to its bound (the room left is below kExactSnap of what it had) is set on it
 #pragma unroll
     for (int i = 0; i < NQ; ++i) y[i] = fma_t(alpha, d[i], y[i]);
-    if (__ballot(cut) != 0ull) {
+    if (cut_lanes != 0ull) {
       each_row_in(first, U, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
         const T m = mu_get(slot);
         T nl = fma_t(alpha, m, l);

@@ -568,7 +568,7 @@ static int build_problem(const Os2rConfig* cfg, int contact_model, const EnvPara
  * (libos2r_oracle.so: what tests/, smoke() and bench.py's cpu_baseline load) every one of them is the compile-time constant of
  * the specification, no setter is exported and the experimental branches are dead code. */
 #ifdef ORC_EXPERIMENTS
-static int g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0;
+static int g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 2, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0;
 static int g_warm = 1, g_first = 3 /* ORC_WARM_FIRST */, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0;
 static double g_incons = 1e-4, g_stall = 0.0;
 static int g_pivot = 0;                  /* 1: an inconsistent-set step that would pin a row it has pinned before in this iteration ends phase 2 instead (round 5) */
@@ -606,7 +606,7 @@ void orc_set_experimental_warm(int mode, int first) {
 }
 long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = g_dbg_counter[which & 3]; if (reset) g_dbg_counter[which & 3] = 0; return v; }
 #else
-enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 3, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
+enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 2, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
        g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0, g_snap = 0, g_solve_first = 0 };
 static const double g_incons = 1e-4, g_stall = 0.0;
@@ -790,7 +790,9 @@ static int block_update_pair(int n, Row* rows, int r0, double* v, double* moved)
  *         the proximal iterations converge at 0.87 per iteration there, the consistency test below takes the set for
  *         inconsistent and the solves zigzag between the two bounds of that row until they are spent, leaving up to 3 % of the
  *         velocity wrong: docs/studies/round5_solver.md),
- *         eps = ORC_EXACT_EPS * trace S (= ORC_EXACT_EPS * |F|),  ORC_EXACT_PROX proximal iterations (d_k from h + eps d_{k-1}) sharpen it;
+ *         eps = ORC_EXACT_EPS * trace S (= ORC_EXACT_EPS * |F|),  ORC_EXACT_PROX = 2 proximal iterations (d_k from h + eps d_{k-1}) sharpen it
+ *         (three up to round 5: with every row at unit length the third changes neither the solves an environment needs nor the
+ *         closed loop -- docs/studies/round5_solver.md 6);
  *         the impulses of the free rows follow from the residuals:  mu_r = -c_r (K w_r + g_r . sum_k d_k) / eps
  *     (the regularisation keeps d in the range of the free rows, and 8 sticking rows in 5 dof are no special case).
  * If the full step would take a free row out of its box, the step is cut at the first bound it meets (that row is set

@@ -105,7 +105,7 @@ def pgs_two_phase(p, normal_iters=3, iters=20, tol=1e-24, group=4):
     return v, lam, box, ran
 
 
-def pgs_exact_finish(p, normal_iters=3, iters=None, tol=1e-24, exact=12, first=None, eps_rel=1e-6, prox=3, snap=1e-12, incons=1e-4,
+def pgs_exact_finish(p, normal_iters=3, iters=None, tol=1e-24, exact=12, first=None, eps_rel=1e-6, prox=2, snap=1e-12, incons=1e-4,
                      small=0, small_pivot=1e-8, equil=True):
     """The specification's solver with the exact finish, restated on the
     exported rows: phase 1 as in pgs_two_phase; phase 2 = `first` sweeps, then -- while the last sweep moved more than
