@@ -1283,6 +1283,12 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
   };
   // live_only: the sweep runs under the mask of a few lanes (the exact finish's loop): a body that none of them touches
   // has reciprocals 0 in all of them -- its rows would reproduce themselves -- and is skipped
+  // (which lanes touch body b, as a lane mask found once: the vote of the lanes at work is then scalar arithmetic on it and the
+  // execution mask -- a vote on `dn[b] > 0` inside the sweep goes through a 0 / 1 vector register and a vector compare whose
+  // result the branch has to wait for)
+  unsigned long long touch[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) touch[b] = ((CMASK >> b) & 1u) ? __builtin_amdgcn_ballot_w64(dn[b] > T(0)) : 0ull;
   auto sweep = [&](auto coupled, auto first, auto measure_, bool live_only = false) {
     constexpr bool measure = decltype(measure_)::value;
     constexpr int kFirst = decltype(first)::value;
@@ -1290,7 +1296,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-      if (live_only && __ballot(dn[b] > T(0)) == 0ull) continue;
+      if (live_only && (touch[b] & __builtin_amdgcn_ballot_w64(true)) == 0ull) continue;
       contact_row(b, 0, erv[b], dn[b], ln[b], T(0), T(0), false, measure);
       if (decltype(coupled)::value) limfix[b] = mub[b] * ln[b];   // the coupled pyramid, experiments only
       const T lim = limfix[b];
@@ -1664,8 +1670,9 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     for (int b = 0; b < NB; ++b) {
       if (!((CMASK >> b) & 1u)) continue;
       if (kFirst >= 0 ? b < kFirst : !wave_act[b]) continue;
-      const bool ap = ((carry.act >> b) & 1u) != 0u && dn[b] > T(0);   // a contact now and in the last iteration
-      if (__ballot(ap) == 0ull) continue;
+      const unsigned long long ap_lanes = touch[b] & __builtin_amdgcn_ballot_w64(((carry.act >> b) & 1u) != 0u);
+      if (ap_lanes == 0ull) continue;
+      const bool ap = __builtin_amdgcn_inverse_ballot_w64(ap_lanes);   // a contact now and in the last iteration
       const T lim = limfix[b];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {

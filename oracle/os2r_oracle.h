@@ -61,7 +61,7 @@ void orc_debug_free_set_hist(long long* out16x12, int reset);   /* diagnostics: 
 void orc_set_experimental_lag_box(int on);   /* studies: 1 -- the lagged friction box (no phase 1 for an environment that remembers every active row) */
 void orc_set_experimental_incons(double threshold);   /* studies: the inconsistent-free-set test's threshold (1e-4) */
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
-void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (3) */
+void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (2; 3 up to round 5) */
 void orc_set_experimental_solve_first(int k);   /* studies (round 5): k > 0 -- an iteration whose predecessor in the env-step took >= k solves opens with a solve instead of the first sweeps */
 void orc_set_experimental_snap(int on);   /* studies (round 5): 1 -- the warm start keeps a tangential row that ended on a bound on the same bound of the new box */
 void orc_set_experimental_multicut(int k);   /* studies (round 5): k > 0 -- a step cut below 1e-k of its length pins every row within 10 x that fraction of its bound at once */

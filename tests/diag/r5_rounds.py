@@ -35,6 +35,7 @@ def apply(L, settings):
             continue
         v = settings.get(k, default)
         getattr(L, fn)(ctypes.c_double(v) if typ is float else int(v))
+    L.orc_set_experimental_warm(1, int(settings.get("first", 3)))   # `first=k`: k warm-started sweeps before the first check
 
 
 def rounds(L, a, settings):
@@ -118,7 +119,7 @@ def main():
         settings = {}
         for kv in filter(None, rest.split(",")):
             k, _, val = kv.partition("=")
-            settings[k] = float(val) if k == "tol" else SWITCHES[k][1](val)
+            settings[k] = float(val) if k == "tol" else (int(val) if k == "first" else SWITCHES[k][1](val))
         print(f"{name}  {settings}  [{a.workload}, {a.envs} envs, {a.steps} env-steps after {a.preroll}]")
         rounds(L, a, settings)
         if a.closed_loop:
