@@ -1622,8 +1622,10 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     }
     // the loop is wave-uniform, what a lane does in it is its own business: a lane whose step was cut solves again
     // while another takes its sweep
-    for (;;) {
-      if (__ballot(live) == 0ull) break;
+    // (rotated by hand -- the vote at the bottom, a guard in front: the compiler does not rotate a loop whose header votes, and
+    // with the exit in the header it copied the 23 loop-carried values -- impulses, velocities -- to a second set of registers
+    // and back at the top of every round)
+    if (__ballot(live) != 0ull) do {
       const bool do_solve = live && solves < pgs_exact;
       if constexpr (COUNT) {
         const unsigned long long sv = __ballot(do_solve);
@@ -1654,7 +1656,7 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
         ++sweeps;
         live = moved > tol_v && sweeps < pgs_iters;
       }
-    }
+    } while (__ballot(live) != 0ull);
   };
   int first_act = NB;
   bool is_suffix = true;
