@@ -1418,7 +1418,11 @@ __device__ __forceinline__ void substep(const MD& md, const Params<T, MD, DR>& p
     // which rows are free for some lane at work here (two or three of the 64, typically, with two free rows each): found once
     // per solve -- the impulses do not move before the last pass -- branch-free, kept as one scalar bit mask
     unsigned U = 0u;
+    const unsigned long long at_work = __builtin_amdgcn_ballot_w64(true);
     each_row(first, [&](int slot, int, const T (&)[NQ], T, T, T& l, T lo, T hi, bool upper) {
+      // (a body that none of the lanes at work touches has its rows switched off in all of them -- impulse 0 in a box [0, 0], never
+      // free --: three votes less per such body, typically one of the three a wave carries when a lone lane is in a burst)
+      if (slot < 3 * NB && (touch[slot / 3] & at_work) == 0ull) return;
       // (a ballot per comparison: the ballot of their conjunction is lowered through a 0 / 1 register and a second compare)
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(l > lo) & (upper ? __builtin_amdgcn_ballot_w64(l < hi) : ~0ull);
       U |= fm != 0ull ? (1u << slot) : 0u;
