@@ -330,7 +330,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--pgs-iters", type=int, default=None, help="cap on the phase-2 sweeps (default: abi.config_struct's: 14 with the exact finish -- 12 below five dof --, 20 without)")
     ap.add_argument("--pgs-exact", type=int, default=None, help="exact free-set solves per physics iteration at most (default 12 in f64; 0: sweeps only, the round-2 solver)")
-    ap.add_argument("--pgs-normal-iters", type=int, default=3)
+    ap.add_argument("--pgs-normal-iters", type=int, default=None, help="normal sweeps that fix the friction box (default: abi.DEFAULT_PGS_NORMAL_ITERS = 2)")
     ap.add_argument("--pgs-tol", type=float, default=None,
                     help="stopping tolerance of the solver's sweeps [J] (default: 1e-24 for f64, 1e-13 for f32; 0: fixed counts)")
     ap.add_argument("--dump-gathered", default=None,

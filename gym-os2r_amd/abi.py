@@ -32,6 +32,11 @@ DONE_BIT, TRUNCATED_BIT, NONFINITE_BIT = 1, 2, 4
 
 # solver defaults (config_struct): sweeps only / with the exact finish
 DEFAULT_PGS_ITERS, DEFAULT_PGS_EXACT = 20, 12
+# normal sweeps that fix the friction box (StdSolver::kNormalIters of csrc/os2r_device.hpp: the kernels compiled for the default
+# settings).  Two since the end of round 5 (three before): after two sweeps the box-fixing normal impulses are within 6e-4 of the
+# converged normal-only solve -- a hundredth of what the fixed box itself is off (6 %: the normal impulses the iteration ends with) --,
+# phase 2 needs the same solves, the closed loop is unchanged (docs/studies/round5_solver.md 9)
+DEFAULT_PGS_NORMAL_ITERS = 2
 
 
 def default_pgs_iters_exact(nq: int) -> int:
@@ -224,11 +229,11 @@ def task_struct(t: Mapping) -> Os2rTaskSpec:
 
 def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = F64,
                   env_offset: int = 0, seed: int = 0, device: int = 0, substeps: int = 10,
-                  dt: float = 1e-4, contact: bool = True, pgs_iters: Optional[int] = None, pgs_normal_iters: int = 3,
+                  dt: float = 1e-4, contact: bool = True, pgs_iters: Optional[int] = None, pgs_normal_iters: Optional[int] = None,
                   auto_reset: bool = True, erp: float = 0.01, max_erv: float = 1e-3,
                   contact_margin: float = 1e-3, pgs_tol: Optional[float] = None,
                   pgs_exact: Optional[int] = None) -> Os2rConfig:
-    """Solver defaults: fp64 -- 3 normal sweeps, then at most `pgs_iters` = 14 (12 below five dof) sweeps over all
+    """Solver defaults: fp64 -- 2 normal sweeps (`pgs_normal_iters`; None: the default), then at most `pgs_iters` = 14 (12 below five dof) sweeps over all
     rows with the exact finish (`pgs_exact` = 12 free-set solves at most per physics iteration); fp32 -- sweeps only
     (20, checked every 4th: the exact finish needs fp64's headroom for its regularised 5 x 5 solve).  Passing
     `pgs_exact=0, pgs_iters=20` selects the round-1/2 solver in fp64 too."""
@@ -242,6 +247,8 @@ def config_struct(model: Mapping, task: Mapping, *, num_envs: int, dtype: int = 
     c.substeps = int(substeps)
     c.dt = float(dt)
     c.contact = 1 if contact else 0
+    if pgs_normal_iters is None:
+        pgs_normal_iters = DEFAULT_PGS_NORMAL_ITERS
     if pgs_exact is None:
         pgs_exact = DEFAULT_PGS_EXACT if dtype == F64 and pgs_normal_iters > 0 else 0
     if pgs_iters is None:

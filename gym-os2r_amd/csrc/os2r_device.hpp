@@ -38,8 +38,8 @@ constexpr int kWave = 64;
 // the solver settings of the default configuration: kernels built for them have compile-time loop bounds (+2 %).
 // fp64: the exact finish with its lower sweep cap; fp32: sweeps only (kExact* below)
 // (kExact: the exact finish is on, with any positive cap on the solves -- the cap stays a run-time value)
-template <typename T> struct StdSolver { static constexpr int kNormalIters = 3; static constexpr bool kExact = true; };
-template <> struct StdSolver<float> { static constexpr int kNormalIters = 3; static constexpr bool kExact = false; };
+template <typename T> struct StdSolver { static constexpr int kNormalIters = 2; static constexpr bool kExact = true; };
+template <> struct StdSolver<float> { static constexpr int kNormalIters = 2; static constexpr bool kExact = false; };
 // The solver state of an environment (round 4): phase 2 of every physics iteration starts from the impulses that ended
 // the environment's previous iteration -- of this env-step or of the one before: the state lives in HBM between the
 // launches (StepArgs::solver_l / solver_flags, os2r_get/set_solver_state), as the reference's backend keeps one persistent

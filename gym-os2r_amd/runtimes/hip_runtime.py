@@ -92,7 +92,7 @@ class HipRuntime:
                  real_time_factor: float = float(np.finfo(np.float32).max), *,
                  num_envs: int = 1, device=None, seed: int = 0, dtype: str = "f64",
                  contact: bool = True, max_episode_steps: int = 0, env_offset: int = 0,
-                 pgs_iters: Optional[int] = None, pgs_normal_iters: int = 3, pgs_exact: Optional[int] = None,
+                 pgs_iters: Optional[int] = None, pgs_normal_iters: Optional[int] = None, pgs_exact: Optional[int] = None,
                  pgs_tol: Optional[float] = None, auto_reset: bool = True, done_reasons: bool = False,
                  physics_engine=None, world: Optional[str] = None, **kwargs):
         steps = physics_rate / agent_rate
@@ -111,7 +111,7 @@ class HipRuntime:
                           # contact solver (abi.config_struct has the defaults: fp64 -- 3 + at most 14 sweeps (12 below five dof) with the exact
                           # finish, 12 solves at most; `pgs_exact=0, pgs_iters=20` is the sweeps-only solver of rounds 1-2;
                           # `pgs_tol` [J] is the stopping tolerance of the sweeps, 1e-24 in fp64 and 1e-13 in fp32)
-                          pgs_iters=None if pgs_iters is None else int(pgs_iters), pgs_normal_iters=int(pgs_normal_iters),
+                          pgs_iters=None if pgs_iters is None else int(pgs_iters), pgs_normal_iters=None if pgs_normal_iters is None else int(pgs_normal_iters),
                           pgs_exact=None if pgs_exact is None else int(pgs_exact),
                           pgs_tol=None if pgs_tol is None else float(pgs_tol), auto_reset=bool(auto_reset),
                           # info['done_reason']: which observation ended each episode (the reference's debug line,

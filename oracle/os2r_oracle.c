@@ -575,6 +575,13 @@ static int g_pivot = 0;                  /* 1: an inconsistent-set step that wou
 void orc_set_experimental_pivot(int on) { g_pivot = on; }
 static int g_snap = 0;                   /* 1: the warm start puts a tangential row that ended the last iteration ON a bound on the same bound of this iteration's box (round 5; within an env-step only) */
 void orc_set_experimental_snap(int on) { g_snap = on; }
+static int g_box_probe = 0;
+static double g_box_stat[4];
+static _Thread_local double tl_boxn[64];
+void orc_set_experimental_box_probe(int on) { g_box_probe = on; for (int i = 0; i < 4; ++i) g_box_stat[i] = 0.0; }
+void orc_debug_box_stat(double* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_box_stat[i]; }
+static int g_warm_p0 = 0;               /* 1: phase 1 (the normal sweeps that fix the friction box) starts from the remembered impulses (round 5 study) */
+void orc_set_experimental_warm_p0(int on) { g_warm_p0 = on; }
 static int g_solve_first = 0;            /* k > 0: a physics iteration whose predecessor IN THE SAME env-step took >= k exact solves skips the first sweeps and opens with a solve (round 5) */
 void orc_set_experimental_solve_first(int k) { g_solve_first = k; }
 static int g_multicut = 0;               /* k > 0: a step that is cut below 1e-k of its length pins every row that would reach its bound within 10 x that fraction, no step taken (round 5) */
@@ -608,7 +615,7 @@ long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = 
 #else
 enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 2, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
-       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0, g_snap = 0, g_solve_first = 0 };
+       g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0, g_snap = 0, g_solve_first = 0, g_warm_p0 = 0 };
 static const double g_incons = 1e-4, g_stall = 0.0;
 #endif
 
@@ -1201,6 +1208,45 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
   }
   for (int phase = 0; phase < 2; ++phase) {
     const int sweeps = phase == 0 ? (fresh ? normal_iters : 0) : iters;
+    if (phase == 0 && g_warm_p0 && sweeps > 0 && exact > 0 && g_warm && !tl_cold && nr <= ORC_WARM_ROWS)
+      for (int r = 0; r < nr; ++r) {   /* (laboratory) phase 1 starts from the remembered normal and joint-friction impulses, not from zero */
+        Row* R = &rows[r];
+        if (R->kind == 1 || !(R->d > 0.0)) continue;
+        const double w0 = tl_warm[warm_slot(rows, r)];
+        if (isnan(w0)) continue;
+        double lo, hi; row_box(rows, R, 1, &lo, &hi);
+        const double nl = w0 < lo ? lo : (w0 > hi ? hi : w0), dl = nl - R->lambda;
+        R->lambda = nl;
+        for (int j = 0; j < n; ++j) v[j] += R->T[j] * dl;
+      }
+#ifdef ORC_EXPERIMENTS
+    if (phase == 1 && normal_iters > 0 && g_box_probe && nr <= 64) {
+      /* (laboratory) how far the normal impulses that fix the friction box are from the converged normal-only solve: 200 more
+       * sweeps of phase 1 on a copy */
+      double l2[64], v2[OS2R_MAX_DOF];
+      for (int r = 0; r < nr; ++r) { l2[r] = rows[r].lambda; tl_boxn[r] = rows[r].lambda; }
+      for (int j = 0; j < n; ++j) v2[j] = v[j];
+      for (int it = 0; it < 200; ++it)
+        for (int r = 0; r < nr; ++r) {
+          const Row* R = &rows[r];
+          if (!(R->d > 0.0) || R->kind == 1) continue;
+          double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v2[j];
+          double lam = l2[r] - res / R->d, lo, hi;
+          row_box(rows, R, 1, &lo, &hi);
+          if (lam < lo) lam = lo;
+          if (lam > hi) lam = hi;
+          const double dl = lam - l2[r];
+          l2[r] = lam;
+          for (int j = 0; j < n; ++j) v2[j] += R->T[j] * dl;
+        }
+      double num = 0.0, den = 0.0;
+      for (int r = 0; r < nr; ++r) if (rows[r].kind == 0 && rows[r].d > 0.0) { num += fabs(rows[r].lambda - l2[r]); den += l2[r]; }
+      #pragma omp atomic
+      g_box_stat[0] += num;
+      #pragma omp atomic
+      g_box_stat[1] += den;
+    }
+#endif
     if (phase == 1 && normal_iters > 0)
       for (int r = 0; r < nr; ++r) if (rows[r].kind == 1) {
         const int nrow = rows[r].normal_row;
@@ -1314,6 +1360,16 @@ static void solve_rows(int n, Row* rows, int nr, int normal_iters, int iters, do
       o += snprintf(buf + o, sizeof(buf) - o, "]}\n");
       FILE* f = fopen(getenv("ORC_DUMP_SOLVES"), "a");
       if (f) { fwrite(buf, 1, (size_t)o, f); fclose(f); }
+    }
+#endif
+#ifdef ORC_EXPERIMENTS
+    if (phase == 1 && normal_iters > 0 && g_box_probe && nr <= 64) {
+      double num = 0.0, den = 0.0;
+      for (int r = 0; r < nr; ++r) if (rows[r].kind == 0 && rows[r].d > 0.0) { num += fabs(tl_boxn[r] - rows[r].lambda); den += rows[r].lambda; }
+      #pragma omp atomic
+      g_box_stat[2] += num;
+      #pragma omp atomic
+      g_box_stat[3] += den;
     }
 #endif
     if (phase == 1) tl_prev_solves = solves;

@@ -9,7 +9,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "C4"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 class A:
     workload = wl; envs_per_gpu = n; dtype = "f64"; seed = 42
-    pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
+    pgs_iters = None; pgs_normal_iters = None; pgs_tol = None; pgs_exact = None; runtime_model = False
 cfg, model, _ = bench.build_config(A, 0, 1)
 o = O.OracleSim(cfg, threads=os.cpu_count() or 1)
 for _ in range(600):

@@ -11,7 +11,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 class A:
     workload = wl; envs_per_gpu = n; dtype = "f64"; seed = 42
-    pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
+    pgs_iters = None; pgs_normal_iters = None; pgs_tol = None; pgs_exact = None; runtime_model = False
 cfg, _, _ = bench.build_config(A, 0, 1)
 L = O.use_laboratory()
 o = O.OracleSim(cfg, threads=os.cpu_count() or 1)

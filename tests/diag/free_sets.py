@@ -7,7 +7,7 @@ from oracle import oracle_py as O
 wl=sys.argv[1] if len(sys.argv)>1 else 'C4'
 class A:
     workload=wl; envs_per_gpu=4096; dtype="f64"; seed=42
-    pgs_iters=None; pgs_normal_iters=3; pgs_tol=None; pgs_exact=None; runtime_model=False
+    pgs_iters=None; pgs_normal_iters=None; pgs_tol=None; pgs_exact=None; runtime_model=False
 cfg,_,_=bench.build_config(A,0,1)
 O.build()
 o=O.OracleSim(cfg,threads=8)

@@ -8,7 +8,7 @@ from oracle import oracle_py as O
 mode=int(sys.argv[1]); wl=sys.argv[2] if len(sys.argv)>2 else 'C4'
 class A:
     workload=wl; envs_per_gpu=8192; dtype="f64"; seed=42
-    pgs_iters=None; pgs_normal_iters=3; pgs_tol=None; pgs_exact=None; runtime_model=False
+    pgs_iters=None; pgs_normal_iters=None; pgs_tol=None; pgs_exact=None; runtime_model=False
 cfg,_,_=bench.build_config(A,0,1)
 O.use_laboratory().orc_set_experimental_warm(mode,0)   # the laboratory build: oracle/Makefile
 o=O.OracleSim(cfg,threads=8)

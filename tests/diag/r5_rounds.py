@@ -25,7 +25,7 @@ from oracle import oracle_py as O     # noqa: E402
 SWITCHES = {"small": ("orc_set_experimental_small", int, 0), "prox": ("orc_set_experimental_prox", int, 2),
             "prox_later": ("orc_set_experimental_prox_later", int, 0), "incons": ("orc_set_experimental_incons", float, 1e-4),
             "stall": ("orc_set_experimental_stall", float, 0.0), "clamp_all": ("orc_set_experimental_clamp_all", int, 0),
-            "incons_once": ("orc_set_experimental_incons_once", int, 0), "pivot": ("orc_set_experimental_pivot", int, 0), "equil": ("orc_set_experimental_equil", int, 1), "repin": ("orc_set_experimental_repin", int, 0), "multicut": ("orc_set_experimental_multicut", int, 0), "snap": ("orc_set_experimental_snap", int, 0), "solve_first": ("orc_set_experimental_solve_first", int, 0)}
+            "incons_once": ("orc_set_experimental_incons_once", int, 0), "pivot": ("orc_set_experimental_pivot", int, 0), "equil": ("orc_set_experimental_equil", int, 1), "repin": ("orc_set_experimental_repin", int, 0), "multicut": ("orc_set_experimental_multicut", int, 0), "snap": ("orc_set_experimental_snap", int, 0), "solve_first": ("orc_set_experimental_solve_first", int, 0), "warm_p0": ("orc_set_experimental_warm_p0", int, 0)}
 
 
 def apply(L, settings):
@@ -41,14 +41,26 @@ def apply(L, settings):
 def rounds(L, a, settings):
     class A:
         workload = a.workload; envs_per_gpu = a.envs; dtype = "f64"; seed = 42
-        pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
+        pgs_iters = None; pgs_normal_iters = None; pgs_tol = None; pgs_exact = None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
+    p1 = int(settings.get("p1", 2))    # (a configuration value: `p1=k` normal sweeps in phase 1; the preroll runs with the default, 2)
     if "tol" in settings:               # (a configuration value, not a switch: `tol=1e-20`)
         cfg.pgs_tol = float(settings["tol"])
     apply(L, {})                       # the preroll is the specification's for every variant: the same states
     o = O.OracleSim(cfg, threads=os.cpu_count() or 1)
     for _ in range(a.preroll):
         o.step(None)
+    if p1 != 2:                        # the same states in a handle with another number of normal sweeps
+        import copy
+        cfg2 = copy.copy(cfg); cfg2.pgs_normal_iters = p1
+        o2 = O.OracleSim(cfg2, threads=os.cpu_count() or 1)
+        o2.set_state(*o.get_state()); o2.set_solver_state(*o.get_solver_state())
+        for w in (0, 1):
+            o2.set_action_history(w, o.get_action_history(w))
+        for f in range(5):
+            o2.set_params(f, o.get_params(f))
+        o2.set_episode_info(*o.episode_info()); o2.step_count = o.step_count
+        o.close(); o = o2
     apply(L, settings)
     o.solver_counts()
     has_small = hasattr(o, "small_solve_counts") and settings.get("small", 0)
@@ -66,7 +78,7 @@ def rounds(L, a, settings):
         # that takes part in it solves in the dual -- approximated by: the lane with the most solves decides the kind of each
         big = (so_ - sm_).max(axis=2)             # regularised solves of the wave's worst lane of that kind
         allr = so_.max(axis=2)
-        M.append((1050.0 * sw_.max(axis=2) + 4200.0 * big + 1400.0 * np.maximum(allr - big, 0)).sum(axis=0))
+        M.append((1050.0 * sw_.max(axis=2) + 4200.0 * big + 1400.0 * np.maximum(allr - big, 0)).sum(axis=0) + 680.0 * p1 * so_.shape[0])
     launch_T, launch_M = np.mean([t.max() for t in T]), np.mean([m.max() for m in M])
     T, M = np.concatenate(T), np.concatenate(M)
     o.close()
@@ -97,10 +109,14 @@ def closed_loop(L, settings):
         o.close()
         return x
     global _REF
-    if "_REF" not in globals():
-        _REF = run({}, pgs_iters=300, pgs_exact=100, pgs_tol=0.0)
+    rule = (int(settings.get("warm_p0", 0)), int(settings.get("p1", 2)))   # (what defines the friction box: the converged reference keeps it)
+    if "_REF" not in globals() or _REF[0] != rule:
+        rs = {k: settings[k] for k in ("warm_p0",) if k in settings}
+        _REF = (rule, run(rs, pgs_iters=300, pgs_exact=100, pgs_tol=0.0, pgs_normal_iters=rule[1]))
     kw = {"pgs_tol": float(settings["tol"])} if "tol" in settings else {}
-    e = np.max(np.abs(run(settings, **kw) - _REF) / np.maximum(np.abs(_REF), 1.0), axis=0)
+    if "p1" in settings:
+        kw["pgs_normal_iters"] = int(settings["p1"])
+    e = np.max(np.abs(run(settings, **kw) - _REF[1]) / np.maximum(np.abs(_REF[1]), 1.0), axis=0)
     print(f"  closed loop, 1000 balancing env-steps vs the converged solve: median {np.median(e):.1e}  p90 {np.percentile(e, 90):.1e}  p99 {np.percentile(e, 99):.1e}  max {e.max():.1e}")
 
 
@@ -119,7 +135,7 @@ def main():
         settings = {}
         for kv in filter(None, rest.split(",")):
             k, _, val = kv.partition("=")
-            settings[k] = float(val) if k == "tol" else (int(val) if k == "first" else SWITCHES[k][1](val))
+            settings[k] = float(val) if k == "tol" else (int(val) if k in ("first", "p1") else SWITCHES[k][1](val))
         print(f"{name}  {settings}  [{a.workload}, {a.envs} envs, {a.steps} env-steps after {a.preroll}]")
         rounds(L, a, settings)
         if a.closed_loop:

@@ -7,7 +7,7 @@ from oracle import oracle_py as O
 wl=sys.argv[1]
 class A:
     workload=wl; envs_per_gpu=8192; dtype="f64"; seed=42
-    pgs_iters=None; pgs_normal_iters=3; pgs_tol=None; pgs_exact=None; runtime_model=False
+    pgs_iters=None; pgs_normal_iters=None; pgs_tol=None; pgs_exact=None; runtime_model=False
 cfg,_,_=bench.build_config(A,0,1)
 O.use_laboratory().orc_set_experimental_small(1)   # the laboratory build: oracle/Makefile
 o=O.OracleSim(cfg,threads=8)

@@ -26,7 +26,7 @@ ap.add_argument("--warm", type=int, default=300)
 ap.add_argument("--windows", type=int, nargs="+", default=[256, 1024, 4096])
 ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
-args = argparse.Namespace(workload="C4", envs_per_gpu=a.envs, seed=42, dtype="f64", pgs_iters=None, pgs_exact=None, pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
+args = argparse.Namespace(workload="C4", envs_per_gpu=a.envs, seed=42, dtype="f64", pgs_iters=None, pgs_exact=None, pgs_normal_iters=None, pgs_tol=None, runtime_model=False)
 cfg, model, spec = bench.build_config(args, 0, 1)
 n, nq = a.envs, cfg.model.nq
 

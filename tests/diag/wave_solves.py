@@ -37,7 +37,7 @@ def main():
 
     class A:
         workload = a.workload; envs_per_gpu = a.envs; dtype = "f64"; seed = 42
-        pgs_iters = None; pgs_normal_iters = 3; pgs_tol = None; pgs_exact = None; runtime_model = False
+        pgs_iters = None; pgs_normal_iters = None; pgs_tol = None; pgs_exact = None; runtime_model = False
     cfg, model, spec = bench.build_config(A, 0, 1)
     L = O.use_laboratory()   # the laboratory build (oracle/Makefile)
     L.orc_set_experimental_warm(int(a.warm), int(a.first))

@@ -441,7 +441,7 @@ def test_two_rank_bench_path_gathers_what_a_single_handle_computes(tmp_path):
     import argparse
     import bench
     from gym_os2r_amd.sim import HipSim
-    ns = argparse.Namespace(workload="C4", envs_per_gpu=131072, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=3,
+    ns = argparse.Namespace(workload="C4", envs_per_gpu=131072, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=None,
                             pgs_tol=1e-24, runtime_model=False)
     cfg, _, _ = bench.build_config(ns, 0, 1)
     sim = HipSim(cfg, device="cuda:0")
@@ -483,7 +483,7 @@ def test_four_rank_bench_path_with_uneven_shards_gathers_what_a_single_handle_co
     import argparse
     import bench
     from gym_os2r_amd.sim import HipSim
-    ns = argparse.Namespace(workload="C4", envs_per_gpu=total, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=3,
+    ns = argparse.Namespace(workload="C4", envs_per_gpu=total, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=None,
                             pgs_tol=1e-24, runtime_model=False)
     cfg, _, _ = bench.build_config(ns, 0, 1)
     sim = HipSim(cfg, device="cuda:0")

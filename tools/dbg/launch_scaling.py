@@ -12,7 +12,7 @@ from gym_os2r_amd.sim import HipSim
 
 
 def run(n, substeps, warm=600, steps=400):
-    args = argparse.Namespace(workload="C4", envs_per_gpu=n, seed=42, dtype="f64", pgs_iters=None, pgs_exact=None, pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
+    args = argparse.Namespace(workload="C4", envs_per_gpu=n, seed=42, dtype="f64", pgs_iters=None, pgs_exact=None, pgs_normal_iters=None, pgs_tol=None, runtime_model=False)
     cfg, _, _ = bench.build_config(args, 0, 1)
     sim = HipSim(cfg)
     sim.reset()

@@ -12,7 +12,7 @@ args = sys.argv[1:]
 steps = int(args.pop()) if args and args[-1].isdigit() else 1200
 for wl in (args or ["V1", "C4"]):
     ns = argparse.Namespace(workload=wl, envs_per_gpu=4096 if wl == "C2" else 65536, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None,
-                            pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
+                            pgs_normal_iters=None, pgs_tol=None, runtime_model=False)
     cfg, _, _ = bench.build_config(ns, 0, 1)
     sim = HipSim(cfg, device="cuda:0")
     print(wl, "per 100 env-steps: [from step] us per launch | done rate | counted over 10 further steps: sweeps, solves per wave-iteration, lanes per solve, bodies in contact per env")

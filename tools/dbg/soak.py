@@ -14,7 +14,7 @@ from gym_os2r_amd.sim import HipSim
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 args = types.SimpleNamespace(workload="C4", envs_per_gpu=65536, seed=7, dtype=sys.argv[2] if len(sys.argv) > 2 else "f64",
-                             pgs_iters=None, pgs_exact=None, pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
+                             pgs_iters=None, pgs_exact=None, pgs_normal_iters=None, pgs_tol=None, runtime_model=False)
 cfg, model, spec = bench.build_config(args, 0, 1)
 sim = HipSim(cfg)
 sim.reset()

@@ -28,7 +28,7 @@ NS = 32   # kStamps in os2r_device.hpp
 def main():
     class A:  # bench.build_config arguments
         workload = sys.argv[1] if len(sys.argv) > 1 else "C4"
-        envs_per_gpu = int(os.environ.get("OS2R_ENVS", "65536")); dtype = "f64"; seed = 42; pgs_normal_iters = 3
+        envs_per_gpu = int(os.environ.get("OS2R_ENVS", "65536")); dtype = "f64"; seed = 42; pgs_normal_iters = None
         pgs_iters = int(os.environ["OS2R_PGS_ITERS"]) if "OS2R_PGS_ITERS" in os.environ else None
         pgs_exact = int(os.environ["OS2R_PGS_EXACT"]) if "OS2R_PGS_EXACT" in os.environ else None
         pgs_tol = float(os.environ["OS2R_PGS_TOL"]) if "OS2R_PGS_TOL" in os.environ else None; runtime_model = False

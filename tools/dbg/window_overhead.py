@@ -10,7 +10,7 @@ from gym_os2r_amd.sim import HipSim
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-args = types.SimpleNamespace(workload="C4", envs_per_gpu=65536, seed=42, dtype="f64", pgs_iters=None, pgs_exact=None, pgs_normal_iters=3, pgs_tol=None, runtime_model=False)
+args = types.SimpleNamespace(workload="C4", envs_per_gpu=65536, seed=42, dtype="f64", pgs_iters=None, pgs_exact=None, pgs_normal_iters=None, pgs_tol=None, runtime_model=False)
 cfg, _, _ = bench.build_config(args, 0, 1)
 sim = HipSim(cfg)
 sim.bench_steps(1200)

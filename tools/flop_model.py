@@ -51,7 +51,7 @@ sys.path.insert(0, ROOT)
 
 def make_sim(workload, envs):
     import bench
-    ns = argparse.Namespace(workload=workload, envs_per_gpu=envs, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=3,
+    ns = argparse.Namespace(workload=workload, envs_per_gpu=envs, dtype="f64", seed=42, pgs_iters=None, pgs_exact=None, pgs_normal_iters=None,
                             pgs_tol=None, runtime_model=False)
     from gym_os2r_amd.sim import HipSim
     cfg, _, _ = bench.build_config(ns, 0, 1)

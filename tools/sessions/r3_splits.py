@@ -14,7 +14,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 
 def run(S, order="round_robin"):
     class A:
-        workload = "C4"; envs_per_gpu = N // S; dtype = "f64"; seed = 42; pgs_iters = None; pgs_exact = None; pgs_normal_iters = 3
+        workload = "C4"; envs_per_gpu = N // S; dtype = "f64"; seed = 42; pgs_iters = None; pgs_exact = None; pgs_normal_iters = None
         pgs_tol = None; runtime_model = False
     sims, streams, bufs = [], [], []
     for i in range(S):
