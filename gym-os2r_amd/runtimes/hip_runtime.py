@@ -108,7 +108,7 @@ class HipRuntime:
         self.num_envs = int(num_envs)
         self._opts = dict(device=device, seed=int(seed), dtype=dtype, contact=bool(contact),
                           max_episode_steps=int(max_episode_steps), env_offset=int(env_offset),
-                          # contact solver (abi.config_struct has the defaults: fp64 -- 3 + at most 14 sweeps (12 below five dof) with the exact
+                          # contact solver (abi.config_struct has the defaults: fp64 -- 2 + at most 14 sweeps (12 below five dof) with the exact
                           # finish, 12 solves at most; `pgs_exact=0, pgs_iters=20` is the sweeps-only solver of rounds 1-2;
                           # `pgs_tol` [J] is the stopping tolerance of the sweeps, 1e-24 in fp64 and 1e-13 in fp32)
                           pgs_iters=None if pgs_iters is None else int(pgs_iters), pgs_normal_iters=None if pgs_normal_iters is None else int(pgs_normal_iters),
