@@ -575,6 +575,8 @@ static int g_pivot = 0;                  /* 1: an inconsistent-set step that wou
 void orc_set_experimental_pivot(int on) { g_pivot = on; }
 static int g_snap = 0;                   /* 1: the warm start puts a tangential row that ended the last iteration ON a bound on the same bound of this iteration's box (round 5; within an env-step only) */
 void orc_set_experimental_snap(int on) { g_snap = on; }
+static double g_margin = 0.0;            /* > 0: free rows keep that fraction of their box width away from the bounds (round 5 study) */
+void orc_set_experimental_margin(double m) { g_margin = m; }
 static int g_box_probe = 0;
 static double g_box_stat[4];
 static _Thread_local double tl_boxn[64];
@@ -616,7 +618,7 @@ long long orc_debug_counter(int which, int reset) { g_dbg_on = 1; long long v = 
 enum { g_block_solve = 0, g_block_kind = 0, g_row_order = 0, g_prox = 2, g_clamp_all = 0, g_small = ORC_EXACT_SMALL_SPEC, g_incons_once = 0, g_lag_box = 0,
        g_warm = 1, g_first = 3, g_solve_always = 0, g_stall_incons_only = 0, g_sweep_after_cut = 0, g_max_rounds = 0, g_stop_at_cap = 0,
        g_trace = 0, g_dbg_on = 0, g_prox_later = 0, g_pivot = 0, g_equil = 1, g_repin = 0, g_multicut = 0, g_snap = 0, g_solve_first = 0, g_warm_p0 = 0 };
-static const double g_incons = 1e-4, g_stall = 0.0;
+static const double g_incons = 1e-4, g_stall = 0.0, g_margin = 0.0;
 #endif
 
 
@@ -933,6 +935,10 @@ static int exact_step(int n, Row* rows, int nr, const double* lc, double* v, int
     const Row* R = &rows[r];
     double lo, hi; row_box(rows, R, 1, &lo, &hi);
     fr[r] = R->d > 0.0 && R->lambda > lo && R->lambda < hi;
+    if (g_margin > 0.0 && fr[r] && isfinite(hi)) {   /* (laboratory) a boxed row within g_margin of its box width from a bound is held where it is */
+      const double m = g_margin * (hi - lo);
+      fr[r] = R->lambda > lo + m && R->lambda < hi - m;
+    }
     if (!fr[r]) continue;
     for (int k = 0; k < n; ++k) { double s = 0; for (int j = k; j < n; ++j) s += R->J[j] * lc[j * n + k]; g[r][k] = s; }
     double res = -R->target; for (int j = 0; j < n; ++j) res += R->J[j] * v[j];

@@ -63,6 +63,7 @@ void orc_set_experimental_incons(double threshold);   /* studies: the inconsiste
 void orc_set_experimental_incons_once(int n);   /* studies: at most n inconsistent-set steps per iteration (0: no limit) */
 void orc_set_experimental_prox(int k);   /* studies: proximal iterations of the regularised solve (2; 3 up to round 5) */
 void orc_set_experimental_solve_first(int k);   /* studies (round 5): k > 0 -- an iteration whose predecessor in the env-step took >= k solves opens with a solve instead of the first sweeps */
+void orc_set_experimental_margin(double m);   /* studies (round 5): free rows keep the fraction m of their box width away from the bounds */
 void orc_set_experimental_box_probe(int on);  /* studies (round 5): accumulate how far the box-fixing normal impulses are from the converged normal-only solve and from the final ones */
 void orc_debug_box_stat(double* out4);
 void orc_set_experimental_warm_p0(int on);   /* studies (round 5): 1 -- phase 1 starts from the remembered normal / joint-friction impulses */

@@ -25,7 +25,7 @@ from oracle import oracle_py as O     # noqa: E402
 SWITCHES = {"small": ("orc_set_experimental_small", int, 0), "prox": ("orc_set_experimental_prox", int, 2),
             "prox_later": ("orc_set_experimental_prox_later", int, 0), "incons": ("orc_set_experimental_incons", float, 1e-4),
             "stall": ("orc_set_experimental_stall", float, 0.0), "clamp_all": ("orc_set_experimental_clamp_all", int, 0),
-            "incons_once": ("orc_set_experimental_incons_once", int, 0), "pivot": ("orc_set_experimental_pivot", int, 0), "equil": ("orc_set_experimental_equil", int, 1), "repin": ("orc_set_experimental_repin", int, 0), "multicut": ("orc_set_experimental_multicut", int, 0), "snap": ("orc_set_experimental_snap", int, 0), "solve_first": ("orc_set_experimental_solve_first", int, 0), "warm_p0": ("orc_set_experimental_warm_p0", int, 0)}
+            "incons_once": ("orc_set_experimental_incons_once", int, 0), "pivot": ("orc_set_experimental_pivot", int, 0), "equil": ("orc_set_experimental_equil", int, 1), "repin": ("orc_set_experimental_repin", int, 0), "multicut": ("orc_set_experimental_multicut", int, 0), "snap": ("orc_set_experimental_snap", int, 0), "solve_first": ("orc_set_experimental_solve_first", int, 0), "warm_p0": ("orc_set_experimental_warm_p0", int, 0), "margin": ("orc_set_experimental_margin", float, 0.0)}
 
 
 def apply(L, settings):
