@@ -518,3 +518,18 @@ def test_flop_model_prices_the_sweep_units_from_the_source():
         k = model[wl]["flops_per_unit"]
         assert k["sweep"] > 0 and k["body_sweep"] > 0 and k["exact_solve"] > 0, (wl, k)
     assert model["C4_f64"]["flops_per_unit"]["sweep"] == joint
+
+
+def test_python_defaults_are_the_compiled_in_standard_solver():
+    """The kernels built for the default solver settings (compile-time loop bounds: StdSolver::kNormalIters, sweep_cap_base +
+    kExactRounds in csrc/os2r_device.hpp) serve a handle only if its configuration says exactly those numbers: the defaults of
+    abi.config_struct must be the header's, or every default handle silently runs the general kernels."""
+    from gym_os2r_amd import abi
+    src = open(os.path.join(ROOT, "gym-os2r_amd", "csrc", "os2r_device.hpp")).read()
+    normal = {int(m) for m in re.findall(r"struct StdSolver[^;]*kNormalIters = (\d+);", src)}
+    assert normal == {abi.DEFAULT_PGS_NORMAL_ITERS}
+    base = re.search(r"constexpr int sweep_cap_base\(int nq\) \{ return nq >= 5 \? (\d+) : (\d+); \}", src)
+    rounds = re.search(r"constexpr int kExactRounds = (\d+);", src)
+    if base and rounds:
+        assert abi.default_pgs_iters_exact(5) == int(base.group(1)) + int(rounds.group(1))
+        assert abi.default_pgs_iters_exact(3) == int(base.group(2)) + int(rounds.group(1))
